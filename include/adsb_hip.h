@@ -1,0 +1,131 @@
+/* adsb_hip.h -- C ABI of libadsb_hip.so: the MI355X (gfx950) replacement for the framer + demod hot
+ * path of mhostetter/gr-adsb.  Plain pointers and sizes only; no exceptions cross this boundary.
+ *
+ * The reference has no native code and therefore no FFI of its own: its two blocks are Python
+ * gr.sync_block subclasses.  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference repo root):
+ *
+ *   adsb_create / adsb_destroy      framer.__init__ python/adsb/framer.py:37-65, demod.__init__ python/adsb/demod.py:35-54
+ *   adsb_set_threshold              framer.set_threshold           python/adsb/framer.py:68-69
+ *   adsb_framer_work                framer.work()                  python/adsb/framer.py:72-182
+ *   adsb_demod_work                 demod.work()                   python/adsb/demod.py:57-136
+ *   adsb_process_iq[_device]        complex_to_mag_squared -> framer -> demod as wired in
+ *                                   examples/adsb_rx.py:180-196 (one canonical work() call per block)
+ *   adsb_process_mag2[_device]      the same chain from the framer's float input onwards
+ *   adsb_shard_*_device / adsb_stitch   (no reference counterpart: overlapped time shards, host stitch)
+ *
+ * Conventions: the caller owns every buffer it passes; the library owns device memory, pinned staging
+ * and one HIP stream per context.  A context is single-threaded; different contexts may be used
+ * concurrently.  Return value 0 = success, negative errno otherwise; when an output array is too
+ * small the call returns -ENOSPC and *n_out holds the required count.  A threshold change takes
+ * effect at the next call.  There is no CPU fallback: without a usable HIP device adsb_create fails.
+ */
+#ifndef ADSB_HIP_H
+#define ADSB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADSB_ABI_VERSION 1
+
+/* adsb_create flags */
+#define ADSB_FLAG_TIMING 1u /* bracket the detect kernel with HIP events (adsb_get_stats) */
+
+/* adsb_burst.flags */
+#define ADSB_BURST_DEMOD 1u /* eob inside the demod input: bits[] valid, a PDU is published (demod.py:82) */
+#define ADSB_BURST_KEPT 2u  /* passed the framer's re-trigger gate (framer.py:121) */
+
+typedef struct adsb_ctx adsb_ctx;
+
+/* One detected burst == one "burst" stream tag (framer.py:168-174) plus, when ADSB_BURST_DEMOD is set,
+ * the payload of the PDU demod would publish for it (demod.py:104-110).  32 bytes, little endian. */
+typedef struct adsb_burst {
+  int64_t offset;   /* absolute stream offset of the tag: centre of the first preamble pulse */
+  float peak;       /* in0[pulse_idx]                       (framer.py:157) */
+  float median;     /* np.median of the <=100 samples before (framer.py:157-159) */
+  uint8_t bits[14]; /* 112 hard bits, first bit = MSB of bits[0] (demod.py:94-95) */
+  uint16_t flags;
+} adsb_burst;
+
+typedef struct adsb_stats {
+  uint64_t detect_launches;  /* k_detect launches timed */
+  double detect_ms;          /* sum of their HIP-event durations */
+  uint64_t detect_samples;   /* samples those launches covered */
+  uint64_t detect_bytes;     /* algorithmic bytes: 8 B (complex64) or 4 B (float |IQ|^2) per sample */
+  uint64_t calls;
+  uint64_t retries;          /* record-capacity regrowths */
+  uint64_t longrun_calls;    /* calls that needed the long-pulse kernel */
+} adsb_stats;
+
+int adsb_abi_version(void);
+
+/* fs must be an even multiple of 1e6 (the reference asserts fs % 1e6 == 0, framer.py:44, and only
+ * works for even sps): otherwise -EINVAL.  device = HIP ordinal. */
+int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx** out);
+void adsb_destroy(adsb_ctx* ctx);
+int adsb_set_threshold(adsb_ctx* ctx, float threshold);
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. */
+int adsb_set_stream(adsb_ctx* ctx, void* hip_stream);
+/* Forget the framer's cross-call state (prev_in0 = 0, prev_eob = -1; framer.py:54,57). */
+int adsb_reset(adsb_ctx* ctx);
+
+/* Canonical whole-buffer mode: ONE framer.work() call over n samples of a fresh stream (history =
+ * 8*sps-1 zeros) followed by ONE demod.work() call over the same n samples with all tags delivered.
+ * iq: n interleaved complex64 (2n floats).  abs_offset: stream offset of sample 0.  Output: the
+ * kept bursts in stream order; bursts whose eob falls outside the buffer have ADSB_BURST_DEMOD clear
+ * (tag emitted, PDU dropped: demod.py:130-133).  Stateless across calls. */
+int adsb_process_iq(adsb_ctx* ctx, const float* iq_host, int64_t n, int64_t abs_offset,
+                    adsb_burst* out, int32_t cap, int32_t* n_out);
+int adsb_process_mag2(adsb_ctx* ctx, const float* mag2_host, int64_t n, int64_t abs_offset,
+                      adsb_burst* out, int32_t cap, int32_t* n_out);
+/* Same, input already in HBM (16-byte aligned device pointer).  out may be NULL: the result stays in
+ * the context's pinned buffer, see adsb_last_result. */
+int adsb_process_iq_device(adsb_ctx* ctx, const void* d_iq, int64_t n, int64_t abs_offset,
+                           adsb_burst* out, int32_t cap, int32_t* n_out);
+int adsb_process_mag2_device(adsb_ctx* ctx, const void* d_mag2, int64_t n, int64_t abs_offset,
+                             adsb_burst* out, int32_t cap, int32_t* n_out);
+int adsb_last_result(adsb_ctx* ctx, const adsb_burst** bursts, int32_t* n);
+
+/* GNU Radio sync-block emulation, framer.work(): in0 holds N + 8*sps - 1 floats of |IQ|^2 (history
+ * first), exactly what the scheduler hands the Python block; nitems_written = nitems_written(0).
+ * Emits the tags of this call (offset/peak/median; flags = KEPT) and carries prev_in0 / prev_eob_idx
+ * inside ctx exactly like the reference (including its stale-state behaviour, framer.py:177-179). */
+int adsb_framer_work(adsb_ctx* ctx, const float* in0, int64_t n_in0, int64_t N, int64_t nitems_written,
+                     adsb_burst* tags, int32_t cap, int32_t* n_out);
+
+/* demod.work(): in0 = this call's n input floats, nitems_read = nitems_read(0) (== nitems_written(0)
+ * for a sync block); tag_offsets = absolute offsets of the "burst" tags inside [nitems_read,
+ * nitems_read+n).  bits112: ntags*112 bytes of 0/1 (the u8vector the PDU carries); ok[t] = 1 when the
+ * burst was demodulated, 0 when it straddles the end of the chunk and is dropped (demod.py:82,130-133).
+ * ratio (optional, may be NULL): ntags*112 floats bit1_amp/bit0_amp; 10*log10 of it is
+ * demod.bit_confidence (demod.py:101). */
+int adsb_demod_work(adsb_ctx* ctx, const float* in0, int64_t n, int64_t nitems_read,
+                    const int64_t* tag_offsets, int32_t ntags, uint8_t* bits112, uint8_t* ok, float* ratio);
+
+/* Overlapped time shards (multi-GPU): the device buffer holds stream samples [origin, origin+n) of
+ * which this shard owns the pulse rises in [own_lo, own_hi) (stream offsets).  stream_len = length of
+ * the whole stream (for the end-of-stream rules); fmt 0 = complex64, 1 = float |IQ|^2.  Returns every matched
+ * preamble centre of the owned range, NOT gated (flags never has KEPT); adsb_stitch applies the gate
+ * over the concatenation.  -EOVERFLOW when a pulse runs past the shard's forward halo. */
+int adsb_shard_device(adsb_ctx* ctx, int fmt, const void* d_data, int64_t n, int64_t origin,
+                      int64_t own_lo, int64_t own_hi, int64_t stream_len,
+                      adsb_burst* out, int32_t cap, int32_t* n_out);
+/* Host stitch: cands = shard outputs concatenated in stream order; applies the re-trigger gate
+ * (framer.py:121-123,165) in place (sets KEPT) and compacts the kept bursts to the front. */
+int adsb_stitch(adsb_burst* cands, int32_t n, int sps, int32_t* n_kept);
+
+/* 10*log10(peak/median) + 1.6 in float32 (framer.py:157). */
+float adsb_snr_db(float peak, float median);
+
+int adsb_get_stats(adsb_ctx* ctx, adsb_stats* out);
+int adsb_reset_stats(adsb_ctx* ctx);
+/* Text of the last error on this context ("" if none). */
+const char* adsb_last_error(adsb_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADSB_HIP_H */

@@ -1,0 +1,198 @@
+// hipsim.h -- TEST INFRASTRUCTURE ONLY: a tiny single-process SIMT emulator that lets the device
+// code in gr_adsb_amd/csrc/adsb_device.h be compiled with g++ and executed on the CPU (no GPU in the
+// build container).  Every HIP thread of a block is a ucontext fiber; __syncthreads() and the
+// wave-level intrinsics (__ballot, __shfl, __shfl_up) are rendezvous points for 256 / 64 fibers.
+// It is used by tests/sim/sim_driver.cpp to check kernel logic against the oracle in `-m "not gpu"`
+// tests.  It is NOT a fallback: nothing under gr_adsb_amd/ includes it and the shipped library
+// contains no CPU path.
+//
+// Restrictions (asserted where possible): blockDim.x is a multiple of 64; wave intrinsics are called
+// by all 64 lanes of a wave in convergent control flow; no thread exits before its wave-mates'
+// last wave intrinsic; blocks run one after another (a `__shared__` array is a function-level static).
+#pragma once
+#include <ucontext.h>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct short4 { short x, y, z, w; };
+struct hipsim_dim3 { unsigned x = 1, y = 1, z = 1; };
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+
+namespace hipsim {
+constexpr int kWave = 64;
+constexpr size_t kStack = 256 * 1024;
+
+struct WaveState {
+  int arrived = 0;
+  unsigned gen = 0;
+  uint64_t slot[2][kWave];
+};
+
+struct Block {
+  int nthreads = 0;
+  int bar_arrived = 0;
+  unsigned bar_gen = 0;
+  std::vector<WaveState> waves;
+  std::vector<ucontext_t> ctx;
+  std::vector<char*> stacks;
+  std::vector<char> done;
+  ucontext_t sched;
+  int cur = -1;
+  int ndone = 0;
+  std::function<void()> body;
+};
+
+inline Block*& cur_block() { static Block* b = nullptr; return b; }
+inline hipsim_dim3& tIdx() { static hipsim_dim3 v; return v; }
+inline hipsim_dim3& bIdx() { static hipsim_dim3 v; return v; }
+inline hipsim_dim3& bDim() { static hipsim_dim3 v; return v; }
+inline hipsim_dim3& gDim() { static hipsim_dim3 v; return v; }
+
+inline void yield() {
+  Block* b = cur_block();
+  int me = b->cur;
+  swapcontext(&b->ctx[me], &b->sched);
+  // resumed: restore my thread index
+  tIdx().x = (unsigned)me;
+}
+
+inline void trampoline() {
+  Block* b = cur_block();
+  int me = b->cur;
+  tIdx().x = (unsigned)me;
+  b->body();
+  b->done[me] = 1;
+  b->ndone++;
+  swapcontext(&b->ctx[me], &b->sched);
+}
+
+inline void run_block(Block& b) {
+  cur_block() = &b;
+  b.ndone = 0;
+  b.bar_arrived = 0;
+  for (int t = 0; t < b.nthreads; ++t) {
+    b.done[t] = 0;
+    getcontext(&b.ctx[t]);
+    b.ctx[t].uc_stack.ss_sp = b.stacks[t];
+    b.ctx[t].uc_stack.ss_size = kStack;
+    b.ctx[t].uc_link = nullptr;
+    makecontext(&b.ctx[t], (void (*)())trampoline, 0);
+  }
+  for (auto& w : b.waves) { w.arrived = 0; }
+  long spins = 0;
+  while (b.ndone < b.nthreads) {
+    for (int t = 0; t < b.nthreads; ++t) {
+      if (b.done[t]) continue;
+      b.cur = t;
+      swapcontext(&b.sched, &b.ctx[t]);
+    }
+    if (++spins > 100000000L) { fprintf(stderr, "hipsim: deadlock (divergent barrier?)\n"); abort(); }
+  }
+  // a thread that exited while others still wait at a barrier is a bug in the kernel under test
+  assert(b.bar_arrived == 0 && "hipsim: block ended with threads parked at __syncthreads");
+}
+
+inline void wave_sync(WaveState& w) {
+  unsigned g = w.gen;
+  if (++w.arrived == kWave) { w.arrived = 0; w.gen++; }
+  else while (w.gen == g) yield();
+}
+
+template <class K, class... A>
+void launch(K kernel, unsigned grid, unsigned block, A... args) {
+  assert(block % kWave == 0);
+  Block b;
+  b.nthreads = (int)block;
+  b.waves.resize(block / kWave);
+  b.ctx.resize(block);
+  b.done.resize(block);
+  b.stacks.resize(block);
+  for (unsigned t = 0; t < block; ++t) b.stacks[t] = (char*)malloc(kStack);
+  bDim().x = block;
+  gDim().x = grid;
+  b.body = [&]() { kernel(args...); };
+  for (unsigned g = 0; g < grid; ++g) {
+    bIdx().x = g;
+    run_block(b);
+  }
+  for (unsigned t = 0; t < block; ++t) free(b.stacks[t]);
+  cur_block() = nullptr;
+}
+}  // namespace hipsim
+
+#define threadIdx (hipsim::tIdx())
+#define blockIdx (hipsim::bIdx())
+#define blockDim (hipsim::bDim())
+#define gridDim (hipsim::gDim())
+
+inline void __syncthreads() {
+  hipsim::Block* b = hipsim::cur_block();
+  unsigned g = b->bar_gen;
+  if (++b->bar_arrived == b->nthreads) { b->bar_arrived = 0; b->bar_gen++; }
+  else while (b->bar_gen == g) hipsim::yield();
+}
+
+inline unsigned long long __ballot(int pred) {
+  hipsim::Block* b = hipsim::cur_block();
+  int me = b->cur, lane = me & 63;
+  hipsim::WaveState& w = b->waves[me >> 6];
+  unsigned par = w.gen & 1;
+  w.slot[par][lane] = pred ? 1 : 0;
+  hipsim::wave_sync(w);
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l) m |= (unsigned long long)(w.slot[par][l] & 1) << l;
+  return m;
+}
+
+template <class T>
+inline T hipsim_shfl_idx(T v, int src) {
+  static_assert(sizeof(T) <= 8, "shfl type too wide");
+  hipsim::Block* b = hipsim::cur_block();
+  int me = b->cur, lane = me & 63;
+  hipsim::WaveState& w = b->waves[me >> 6];
+  unsigned par = w.gen & 1;
+  uint64_t raw = 0;
+  memcpy(&raw, &v, sizeof(T));
+  w.slot[par][lane] = raw;
+  hipsim::wave_sync(w);
+  uint64_t r = w.slot[par][src & 63];
+  T out;
+  memcpy(&out, &r, sizeof(T));
+  return out;
+}
+template <class T> inline T __shfl(T v, int src) { return hipsim_shfl_idx(v, src); }
+template <class T> inline T __shfl_up(T v, unsigned d) {
+  int lane = hipsim::cur_block()->cur & 63;
+  int src = lane - (int)d;
+  T r = hipsim_shfl_idx(v, src < 0 ? lane : src);
+  return r;
+}
+
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline unsigned long long __brevll(unsigned long long v) {
+  unsigned long long r = 0;
+  for (int i = 0; i < 64; ++i) r |= ((v >> i) & 1ull) << (63 - i);
+  return r;
+}
+inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+
+template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }

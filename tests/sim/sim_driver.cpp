@@ -1,0 +1,139 @@
+// sim_driver.cpp -- TEST INFRASTRUCTURE ONLY.  Compiles the product's device code
+// (gr_adsb_amd/csrc/adsb_device.h) against the SIMT emulator in hipsim.h and runs the same kernel
+// sequence the library launches, on host memory, so that kernel logic can be checked against the
+// oracle in the GPU-less build container.  Never linked into libadsb_hip.so.
+#include "hipsim.h"
+
+#include "../../gr_adsb_amd/csrc/adsb_device.h"
+#include "../../gr_adsb_amd/csrc/adsb_plan.h"
+
+#include <vector>
+
+using namespace adsb;
+
+extern "C" {
+
+struct SimOut {
+  int n_rec, n_kept, overflow, long_count;
+  unsigned flags;
+  long long lastp, last_kept;
+};
+
+// mode 0: data = complex64 (2n floats); mode 1: data = float |IQ|^2.  Returns 0 or -1 (overflow of out).
+int sim_run(int mode, const float* data, long long n, long long in0_base, long long scan_lo, long long scan_hi,
+            long long fall_hi, long long dem_hi, long long origin, float thr, float prev_in0, int sps,
+            int end_is_call_end, long long prev_eob_stream, int gate, int grid_max, int rec_cap_in,
+            unsigned long long* out_recs /* 4 words each */, int out_cap, SimOut* so) {
+  const long long span = scan_hi > 0 ? scan_hi : 0;
+  long long ntiles = (span + kTile - 1) / kTile;
+  if (ntiles < 1) ntiles = 1;
+  int grid = (int)(ntiles < grid_max ? ntiles : grid_max);
+  const long long tiles_per = (ntiles + grid - 1) / grid;
+  grid = (int)((ntiles + tiles_per - 1) / tiles_per);
+  const long long chunk = tiles_per * kTile;
+  const int rec_cap = rec_cap_in > 0 ? rec_cap_in : (int)(chunk / 2 + 8);
+  const long long tot = (long long)grid * rec_cap;
+
+  // data must be 16-byte aligned like a device allocation
+  const size_t nfl = (size_t)n * (mode == 0 ? 2 : 1);
+  float* dbuf = (float*)aligned_alloc(64, ((nfl * 4 + 63) / 64 + 1) * 64);
+  memcpy(dbuf, data, nfl * 4);
+
+  std::vector<Rec> recs(tot), sorted(tot), outv(tot);
+  std::vector<int> blk_count(grid), blk_off(grid), seg(tot / kThreads + 2);
+  std::vector<long long> blk_lastp(grid);
+  std::vector<unsigned> blk_flags(grid);
+  std::vector<LongRise> longlist(ntiles + 1);
+  int long_count = 0;
+  unsigned long long long_lastp = 0;
+  Summary sum;
+
+  DetectArgs a;
+  a.data = dbuf; a.n = n; a.in0_base = in0_base; a.scan_lo = scan_lo; a.scan_hi = scan_hi; a.fall_hi = fall_hi;
+  a.dem_hi = dem_hi; a.origin = origin; a.chunk = chunk; a.thr = thr; a.prev_in0 = prev_in0; a.sps = sps;
+  a.end_is_call_end = end_is_call_end; a.rec_cap = rec_cap; a.long_cap = (int)(ntiles + 1);
+  a.recs = recs.data(); a.blk_count = blk_count.data(); a.blk_lastp = blk_lastp.data();
+  a.blk_flags = blk_flags.data(); a.longlist = longlist.data(); a.long_count = &long_count;
+  a.long_lastp = &long_lastp;
+
+  if (mode == 0) hipsim::launch(k_detect<0>, grid, kThreads, a);
+  else hipsim::launch(k_detect<1>, grid, kThreads, a);
+
+  bool did_long = false;
+  for (;;) {
+    hipsim::launch(k_scan, 1, kThreads, (const int*)blk_count.data(), (const long long*)blk_lastp.data(),
+                   (const unsigned*)blk_flags.data(), grid, rec_cap, (const int*)&long_count,
+                   (const unsigned long long*)&long_lastp, blk_off.data(), &sum);
+    hipsim::launch(k_gather, grid < 8 ? grid : 8, kThreads, (const Rec*)recs.data(), (const int*)blk_count.data(),
+                   (const int*)blk_off.data(), grid, rec_cap, sorted.data());
+    if (gate) {
+      hipsim::launch(k_resolve, 3, kThreads, sorted.data(), (const Summary*)&sum, (long long)63 * sps,
+                     prev_eob_stream, seg.data());
+      hipsim::launch(k_count, 3, kThreads, (const Rec*)sorted.data(), (const Summary*)&sum, seg.data());
+      hipsim::launch(k_scan2, 1, kThreads, seg.data(), &sum, (const Rec*)sorted.data());
+      hipsim::launch(k_compact, 3, kThreads, (const Rec*)sorted.data(), (const Summary*)&sum, (const int*)seg.data(),
+                     outv.data(), (int)tot);
+    }
+    if (sum.long_count > 0 && !did_long && !sum.overflow) {
+      did_long = true;
+      int nl = sum.long_count;
+      if (mode == 0) hipsim::launch(k_longrun<0>, nl < 4 ? nl : 4, kThreads, a, nl);
+      else hipsim::launch(k_longrun<1>, nl < 4 ? nl : 4, kThreads, a, nl);
+      continue;
+    }
+    break;
+  }
+  so->n_rec = sum.n_rec; so->n_kept = sum.n_kept; so->overflow = sum.overflow; so->long_count = sum.long_count;
+  so->flags = sum.flags; so->lastp = sum.lastp; so->last_kept = sum.last_kept_p;
+  const int nres = gate ? sum.n_kept : sum.n_rec;
+  const Rec* src = gate ? outv.data() : sorted.data();
+  free(dbuf);
+  if (nres > out_cap) return -1;
+  memcpy(out_recs, src, (size_t)nres * sizeof(Rec));
+  return 0;
+}
+
+// --- the library's three call shapes, through the same adsb_plan.h the library uses ------------------
+int sim_canonical(int mode, const float* data, long long n, long long abs_offset, float thr, int sps, int grid_max,
+                  int rec_cap, unsigned long long* out, int out_cap, SimOut* so) {
+  Plan p = plan_canonical(mode, data, n, abs_offset, sps);
+  return sim_run(mode, data, n, p.in0_base, p.scan_lo, p.scan_hi, p.fall_hi, p.dem_hi, p.origin, thr, p.prev_in0, sps,
+                 p.end_is_call_end, p.prev_eob_stream, 1, grid_max, rec_cap, out, out_cap, so);
+}
+
+// state[0] = prev_in0 (float bits in a double), state[1] = prev_eob
+int sim_framer_work(const float* in0, long long n_in0, long long N, long long nitems_written, float thr, int sps,
+                    float* prev_in0, long long* prev_eob, int grid_max, unsigned long long* out, int out_cap,
+                    SimOut* so) {
+  FramerState st;
+  st.prev_in0 = *prev_in0; st.prev_eob = *prev_eob;
+  Plan p = plan_framer_work(in0, n_in0, N, nitems_written, sps, st);
+  int rc = sim_run(1, in0, n_in0, p.in0_base, p.scan_lo, p.scan_hi, p.fall_hi, p.dem_hi, p.origin, thr, p.prev_in0, sps,
+                   p.end_is_call_end, p.prev_eob_stream, 1, grid_max, 0, out, out_cap, so);
+  if (rc) return rc;
+  framer_state_update(st, in0[N - 1], N, sps, so->flags, so->lastp, kNoIndex, so->n_kept,
+                      so->n_kept > 0 ? so->last_kept - p.origin : 0);
+  *prev_in0 = st.prev_in0; *prev_eob = st.prev_eob;
+  return 0;
+}
+
+int sim_shard(int mode, const float* data, long long n, long long origin, long long own_lo, long long own_hi,
+              long long stream_len, float thr, int sps, int grid_max, unsigned long long* out, int out_cap, SimOut* so) {
+  Plan p = plan_shard(mode, data, n, origin, own_lo, own_hi, stream_len, sps);
+  return sim_run(mode, data, n, p.in0_base, p.scan_lo, p.scan_hi, p.fall_hi, p.dem_hi, p.origin, thr, p.prev_in0, sps,
+                 p.end_is_call_end, p.prev_eob_stream, 0, grid_max, 0, out, out_cap, so);
+}
+
+// k_slice for a tag list (demod block emulation)
+int sim_slice(const float* in0, long long n, const long long* tag_idx, int ntags, int sps, unsigned char* bits14,
+              unsigned char* ok, float* ratio) {
+  float* dbuf = (float*)aligned_alloc(64, (((size_t)n * 4 + 63) / 64 + 1) * 64);
+  memcpy(dbuf, in0, (size_t)n * 4);
+  int nb = (ntags + kWaves - 1) / kWaves;
+  if (nb > 4) nb = 4;
+  if (nb < 1) nb = 1;
+  hipsim::launch(k_slice<1>, nb, kThreads, (const void*)dbuf, n, tag_idx, ntags, sps, bits14, ok, ratio);
+  free(dbuf);
+  return 0;
+}
+}

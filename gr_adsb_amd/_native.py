@@ -1,0 +1,211 @@
+"""ctypes binding of libadsb_hip.so (C ABI: include/adsb_hip.h).
+
+The product path: there is NO CPU implementation behind this module.  If the shared library is
+missing, or no HIP device can be opened, the import / constructor raises -- it never falls back.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libadsb_hip.so")
+
+BURST_DTYPE = np.dtype([("offset", "<i8"), ("peak", "<f4"), ("median", "<f4"), ("bits", "u1", (14,)), ("flags", "<u2")])
+assert BURST_DTYPE.itemsize == 32
+
+FLAG_TIMING = 1
+BURST_DEMOD = 1
+BURST_KEPT = 2
+
+EXPORTS = [
+    "adsb_abi_version", "adsb_create", "adsb_destroy", "adsb_set_threshold", "adsb_set_stream", "adsb_reset",
+    "adsb_process_iq", "adsb_process_mag2", "adsb_process_iq_device", "adsb_process_mag2_device", "adsb_last_result",
+    "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_stitch", "adsb_snr_db", "adsb_get_stats",
+    "adsb_reset_stats", "adsb_last_error",
+]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("detect_launches", ctypes.c_uint64), ("detect_ms", ctypes.c_double), ("detect_samples", ctypes.c_uint64),
+                ("detect_bytes", ctypes.c_uint64), ("calls", ctypes.c_uint64), ("retries", ctypes.c_uint64),
+                ("longrun_calls", ctypes.c_uint64)]
+
+
+class AdsbError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libadsb_hip: error %d (%s)%s" % (code, os.strerror(-code) if code < 0 else "?", ": " + msg if msg else ""))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library; raises if it has not been built (python -m gr_adsb_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libadsb_hip.so not built: run `python -m gr_adsb_amd.build` (hipcc, gfx950). "
+                          "There is no CPU fallback for the ADS-B hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, i64, i32, f32 = c.c_void_p, c.c_int64, c.c_int32, c.c_float
+    lib.adsb_abi_version.restype = c.c_int
+    lib.adsb_create.argtypes = [c.c_double, f32, c.c_int, c.c_uint32, c.POINTER(vp)]
+    lib.adsb_destroy.argtypes = [vp]
+    lib.adsb_destroy.restype = None
+    lib.adsb_set_threshold.argtypes = [vp, f32]
+    lib.adsb_set_stream.argtypes = [vp, vp]
+    lib.adsb_reset.argtypes = [vp]
+    for name in ("adsb_process_iq", "adsb_process_mag2", "adsb_process_iq_device", "adsb_process_mag2_device"):
+        getattr(lib, name).argtypes = [vp, vp, i64, i64, vp, i32, c.POINTER(i32)]
+    lib.adsb_last_result.argtypes = [vp, c.POINTER(vp), c.POINTER(i32)]
+    lib.adsb_framer_work.argtypes = [vp, vp, i64, i64, i64, vp, i32, c.POINTER(i32)]
+    lib.adsb_demod_work.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp, vp]
+    lib.adsb_shard_device.argtypes = [vp, c.c_int, vp, i64, i64, i64, i64, i64, vp, i32, c.POINTER(i32)]
+    lib.adsb_stitch.argtypes = [vp, i32, c.c_int, c.POINTER(i32)]
+    lib.adsb_snr_db.argtypes = [f32, f32]
+    lib.adsb_snr_db.restype = f32
+    lib.adsb_get_stats.argtypes = [vp, c.POINTER(Stats)]
+    lib.adsb_reset_stats.argtypes = [vp]
+    lib.adsb_last_error.argtypes = [vp]
+    lib.adsb_last_error.restype = c.c_char_p
+    _lib = lib
+    return lib
+
+
+class Context:
+    """Owns one adsb_ctx (one HIP device + stream).  Thin: every method is one C-ABI call."""
+
+    def __init__(self, fs, threshold, device=0, flags=0):
+        self.lib = load()
+        self.fs = float(fs)
+        self.sps = int(fs // 1e6)
+        self._h = ctypes.c_void_p()
+        rc = self.lib.adsb_create(float(fs), float(np.float32(threshold)), int(device), int(flags), ctypes.byref(self._h))
+        if rc != 0:
+            self._h = ctypes.c_void_p()
+            raise AdsbError(rc, "adsb_create(fs=%r, device=%r) failed; a HIP device is required" % (fs, device))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.adsb_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise AdsbError(rc, self.lib.adsb_last_error(self._h).decode("utf-8", "replace"))
+
+    def set_threshold(self, thr):
+        self._chk(self.lib.adsb_set_threshold(self._h, float(np.float32(thr))))
+
+    def set_stream(self, stream_handle):
+        self._chk(self.lib.adsb_set_stream(self._h, ctypes.c_void_p(int(stream_handle))))
+
+    def reset(self):
+        self._chk(self.lib.adsb_reset(self._h))
+
+    def _run(self, fn, ptr, n, abs_offset):
+        n_out = ctypes.c_int32(0)
+        self._chk(fn(self._h, ctypes.c_void_p(ptr), int(n), int(abs_offset), None, 0, ctypes.byref(n_out)))
+        return self.last_result()
+
+    def last_result(self):
+        p = ctypes.c_void_p()
+        n = ctypes.c_int32(0)
+        self._chk(self.lib.adsb_last_result(self._h, ctypes.byref(p), ctypes.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=BURST_DTYPE)
+        buf = (ctypes.c_char * (n.value * 32)).from_address(p.value)
+        return np.frombuffer(buf, dtype=BURST_DTYPE).copy()
+
+    def process_iq(self, iq, abs_offset=0):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        return self._run(self.lib.adsb_process_iq, iq.ctypes.data, len(iq), abs_offset)
+
+    def process_mag2(self, x, abs_offset=0):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        return self._run(self.lib.adsb_process_mag2, x.ctypes.data, len(x), abs_offset)
+
+    def process_iq_device(self, dev_ptr, n, abs_offset=0, fetch=True):
+        n_out = ctypes.c_int32(0)
+        self._chk(self.lib.adsb_process_iq_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(n), int(abs_offset), None, 0,
+                                                  ctypes.byref(n_out)))
+        return self.last_result() if fetch else n_out.value
+
+    def process_mag2_device(self, dev_ptr, n, abs_offset=0, fetch=True):
+        n_out = ctypes.c_int32(0)
+        self._chk(self.lib.adsb_process_mag2_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(n), int(abs_offset), None, 0,
+                                                    ctypes.byref(n_out)))
+        return self.last_result() if fetch else n_out.value
+
+    def framer_work(self, in0, N, nitems_written):
+        in0 = np.ascontiguousarray(in0, dtype=np.float32)
+        n_out = ctypes.c_int32(0)
+        self._chk(self.lib.adsb_framer_work(self._h, ctypes.c_void_p(in0.ctypes.data), len(in0), int(N), int(nitems_written),
+                                            None, 0, ctypes.byref(n_out)))
+        return self.last_result()
+
+    def demod_work(self, in0, nitems_read, tag_offsets, want_ratio=False):
+        in0 = np.ascontiguousarray(in0, dtype=np.float32)
+        tags = np.ascontiguousarray(tag_offsets, dtype=np.int64)
+        nt = len(tags)
+        bits = np.zeros((nt, 112), dtype=np.uint8)
+        ok = np.zeros(nt, dtype=np.uint8)
+        ratio = np.zeros((nt, 112), dtype=np.float32) if want_ratio else None
+        self._chk(self.lib.adsb_demod_work(self._h, ctypes.c_void_p(in0.ctypes.data), len(in0), int(nitems_read),
+                                           ctypes.c_void_p(tags.ctypes.data), nt, ctypes.c_void_p(bits.ctypes.data),
+                                           ctypes.c_void_p(ok.ctypes.data),
+                                           ctypes.c_void_p(ratio.ctypes.data) if want_ratio else None))
+        return bits, ok.astype(bool), ratio
+
+    def shard_device(self, fmt, dev_ptr, n, origin, own_lo, own_hi, stream_len):
+        n_out = ctypes.c_int32(0)
+        self._chk(self.lib.adsb_shard_device(self._h, int(fmt), ctypes.c_void_p(int(dev_ptr)), int(n), int(origin), int(own_lo),
+                                             int(own_hi), int(stream_len), None, 0, ctypes.byref(n_out)))
+        return self.last_result()
+
+    def stats(self):
+        s = Stats()
+        self._chk(self.lib.adsb_get_stats(self._h, ctypes.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def reset_stats(self):
+        self._chk(self.lib.adsb_reset_stats(self._h))
+
+
+def stitch(cands, sps):
+    """Host stitch of shard candidate lists (already concatenated in stream order)."""
+    lib = load()
+    cands = np.ascontiguousarray(cands, dtype=BURST_DTYPE).copy()
+    nk = ctypes.c_int32(0)
+    rc = lib.adsb_stitch(ctypes.c_void_p(cands.ctypes.data), len(cands), int(sps), ctypes.byref(nk))
+    if rc != 0:
+        raise AdsbError(rc, "adsb_stitch")
+    return cands[:nk.value]
+
+
+def snr_db_c(peak, median):
+    return load().adsb_snr_db(float(peak), float(median))
+
+
+def unpack_bits(bits14):
+    """[n,14] packed bytes -> [n,112] 0/1 uint8 (the u8vector layout of the reference PDU)."""
+    return np.unpackbits(np.asarray(bits14, dtype=np.uint8).reshape(-1, 14), axis=1, bitorder="big")
+
+
+def snr_db(peak, median):
+    """10*log10(peak/median)+1.6 in float32 with NumPy itself, so the bits equal the reference's
+    (framer.py:157 under NumPy-2 promotion) on whatever host this runs on."""
+    with np.errstate(all="ignore"):
+        p = np.asarray(peak, dtype=np.float32)
+        m = np.asarray(median, dtype=np.float32)
+        return (np.float32(10.0) * np.log10(p / m) + np.float32(1.6)).astype(np.float32)

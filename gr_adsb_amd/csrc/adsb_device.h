@@ -158,7 +158,8 @@ __device__ void emit_record(const Acc& acc, const DetectArgs& a, long long p, Re
     const float sd = __shfl(v1, l1 ? __builtin_ctzll(l1) : 0);
     const float hi = h0 ? sa : sb;
     const float lo = l0 ? sc : sd;
-    if (nwin == 0 || nanm) med = __builtin_nanf("");
+    if (nwin == 0) med = __builtin_bit_cast(float, 0xFFC00000u);   // np.median([]) == 0/0: default NaN, sign set
+    else if (nanm) med = __builtin_bit_cast(float, 0x7FC00000u);    // a NaN in the window propagates
     else if (nwin & 1) med = hi;
     else med = __fmul_rn(__fadd_rn(lo, hi), 0.5f);     // f32(a+b)/2
   }

@@ -1,0 +1,80 @@
+"""Whole-buffer and sharded front end over the C ABI: the bulk (bench) path.
+
+FrontEnd.process_* == one canonical framer.work() + demod.work() over a buffer (SURVEY.md §8a chunk
+semantics); shard_plan/process_shard/stitch tile a long stream across GPUs as independent overlapped
+time shards whose candidate lists are stitched on the host -- no collective.
+"""
+import numpy as np
+
+from . import _native
+
+NOISE_BACK = 100          # framer.py:31 look-back for the SNR median
+
+
+def shard_plan(stream_len, n_shards, sps, max_run=256, align=4096):
+    """Split [0, stream_len) into n_shards owner ranges with the halos each one needs:
+    back = 100 (noise median) + 1, forward = max_run (longest pulse followed) + 120*sps (preamble +
+    112 bits).  Returns a list of dicts(own_lo, own_hi, lo, hi) in stream offsets; buffer starts are
+    aligned down to 4 samples (16-byte loads)."""
+    per = -(-stream_len // n_shards)
+    per = -(-per // align) * align
+    plans = []
+    for g in range(n_shards):
+        own_lo = min(stream_len, g * per)
+        own_hi = min(stream_len, (g + 1) * per)
+        lo = max(0, own_lo - (NOISE_BACK + 8 * sps + 4))
+        lo -= lo % 4
+        hi = min(stream_len, own_hi + max_run + 121 * sps)
+        plans.append(dict(own_lo=own_lo, own_hi=own_hi, lo=lo, hi=hi))
+    return plans
+
+
+class FrontEnd:
+    def __init__(self, fs, threshold, device=0, timing=False):
+        self.fs = float(fs)
+        self.sps = int(fs // 1e6)
+        self.ctx = _native.Context(fs, threshold, device=device, flags=_native.FLAG_TIMING if timing else 0)
+
+    def set_threshold(self, thr):
+        self.ctx.set_threshold(thr)
+
+    def use_torch_stream(self, stream):
+        self.ctx.set_stream(stream.cuda_stream)
+
+    # -- host buffers -------------------------------------------------------------------------------
+    def process_iq(self, iq, abs_offset=0):
+        return self.ctx.process_iq(iq, abs_offset)
+
+    def process_mag2(self, x, abs_offset=0):
+        return self.ctx.process_mag2(x, abs_offset)
+
+    # -- torch tensors already in HBM ---------------------------------------------------------------
+    def process_iq_tensor(self, t, abs_offset=0, fetch=True):
+        """t: float32 [n,2] (or complex64 [n]) CUDA tensor, contiguous."""
+        assert t.is_cuda and t.is_contiguous()
+        n = t.shape[0]
+        return self.ctx.process_iq_device(t.data_ptr(), n, abs_offset, fetch=fetch)
+
+    def process_mag2_tensor(self, t, abs_offset=0, fetch=True):
+        assert t.is_cuda and t.is_contiguous()
+        return self.ctx.process_mag2_device(t.data_ptr(), t.shape[0], abs_offset, fetch=fetch)
+
+    def shard_tensor(self, t, origin, own_lo, own_hi, stream_len, fmt=0):
+        assert t.is_cuda and t.is_contiguous()
+        return self.ctx.shard_device(fmt, t.data_ptr(), t.shape[0], origin, own_lo, own_hi, stream_len)
+
+    def stitch(self, cand_lists):
+        c = np.concatenate([np.asarray(x, dtype=_native.BURST_DTYPE) for x in cand_lists]) if len(cand_lists) else \
+            np.zeros(0, dtype=_native.BURST_DTYPE)
+        return _native.stitch(c, self.sps)
+
+    def stats(self):
+        return self.ctx.stats()
+
+    @staticmethod
+    def snr(bursts):
+        return _native.snr_db(bursts["peak"], bursts["median"])
+
+    @staticmethod
+    def bits(bursts):
+        return _native.unpack_bits(bursts["bits"])[:, :112]

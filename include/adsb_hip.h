@@ -117,7 +117,9 @@ int adsb_shard_device(adsb_ctx* ctx, int fmt, const void* d_data, int64_t n, int
  * (framer.py:121-123,165) in place (sets KEPT) and compacts the kept bursts to the front. */
 int adsb_stitch(adsb_burst* cands, int32_t n, int sps, int32_t* n_kept);
 
-/* 10*log10(peak/median) + 1.6 in float32 (framer.py:157). */
+/* 10*log10(peak/median) + 1.6 in float32 (framer.py:157) with libm's log10f.  NumPy's float32 log10 is
+ * a SIMD routine on some hosts, so the reference's SNR bits are host dependent; the Python shim finalises
+ * SNR with NumPy from (peak, median) -- those two ARE bit exact -- and this helper is for C callers. */
 float adsb_snr_db(float peak, float median);
 
 int adsb_get_stats(adsb_ctx* ctx, adsb_stats* out);

@@ -1,0 +1,134 @@
+/* adsb_oracle.c -- CPU ORACLE (test infrastructure, NOT product code): a scalar C restatement of the
+ * gr-adsb framer + demod hot path in canonical whole-buffer mode (one framer.work() call over a
+ * fresh stream, one demod.work() call over the same samples, all tags delivered).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; nothing under
+ * gr_adsb_amd/ does.  It is pinned against oracle/adsb_oracle.py (which is pinned against the real
+ * reference, see that file's header) by tests/test_oracle_c.py, and used where the NumPy oracle is
+ * too slow: full-size parity checks and the single-core CPU baseline ("kind": "port").
+ *
+ * Citations are to /root/reference/python/adsb/.  |IQ|^2 (GNU Radio complex_to_mag_squared,
+ * examples/adsb_rx.py:180) is parity-unpinned by the reference's tests and defined as float32
+ * re*re + im*im with separately rounded products; build with -ffp-contract=off.
+ *
+ * Output record layout (32 bytes) matches include/adsb_hip.h's adsb_burst so results compare bytewise.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+  int64_t offset;
+  float peak;
+  float median;
+  uint8_t bits[14];
+  uint16_t flags; /* 1 = demodulated (PDU published), 2 = kept (tag emitted) */
+} orec;
+
+static const int TEMPLATE[16] = {1, 0, 1, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0}; /* framer.py:50 */
+
+/* np.median of w[0:n] in float32: odd -> middle, even -> f32(a+b)/2, NaN if n == 0 or any NaN */
+static float median_f32(const float* w, int n) {
+  float s[100];
+  if (n <= 0) { union { uint32_t u; float f; } q; q.u = 0xFFC00000u; return q.f; }  /* np.median([]) = 0/0 */
+  for (int i = 0; i < n; ++i) {
+    if (w[i] != w[i]) return NAN;
+    float v = w[i];
+    int j = i;
+    while (j > 0 && s[j - 1] > v) { s[j] = s[j - 1]; --j; }
+    s[j] = v;
+  }
+  if (n & 1) return s[n / 2];
+  volatile float sum = s[n / 2 - 1] + s[n / 2];
+  return sum / 2.0f;
+}
+
+void oracle_mag2(const float* iq, int64_t n, float* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    volatile float a = iq[2 * i] * iq[2 * i];
+    volatile float b = iq[2 * i + 1] * iq[2 * i + 1];
+    out[i] = a + b;
+  }
+}
+
+/* x: float32 |IQ|^2 stream of length n.  Returns number of tags written (or -needed if cap too small;
+ * the first `cap` are still written).  If cands != NULL every matched centre's stream offset (before the
+ * re-trigger gate) is stored there, up to cand_cap, count in *n_cands. */
+int64_t oracle_canonical(const float* x, int64_t n, int sps, float thr, int64_t abs_offset, orec* out, int64_t cap,
+                         int64_t* cands, int64_t cand_cap, int64_t* n_cands) {
+  const int64_t H = 8 * (int64_t)sps;       /* framer.py:61 */
+  const int half = sps / 2;
+  const int64_t N = n;                      /* one call: N = len(out0) */
+  float* in0 = (float*)calloc((size_t)(n + H), sizeof(float));
+  if (!in0) return -1;
+  memcpy(in0 + (H - 1), x, (size_t)n * sizeof(float));   /* history of H-1 zeros, then the stream */
+  int64_t ntags = 0, ncand = 0;
+  int64_t eob = -1;                          /* framer.py:57 */
+  int prev = (0.0f >= thr);                  /* framer.py:54,84: prev_in0 = 0 */
+  int64_t rise = -1;
+  for (int64_t j = 0; j < N; ++j) {
+    const int a = (in0[j] >= thr);           /* framer.py:84 (float32 compare; NaN -> 0) */
+    if (a && !prev) rise = j;                /* framer.py:92 */
+    if (!a && prev && rise >= 0) {           /* framer.py:93,98-100: a fall with no rise in this call is dropped */
+      const int64_t p = (rise + j) / 2;      /* framer.py:113 */
+      rise = -1;
+      if (p > eob) {                         /* framer.py:121 */
+        eob = -1;                            /* framer.py:123 */
+        const float hp = in0[p] / 2.0f;      /* framer.py:141 */
+        int ok = 1;
+        for (int k = 0; k < 16; ++k) {       /* framer.py:137-147 */
+          const int chip = in0[p + (int64_t)k * half] > hp;
+          if (chip != TEMPLATE[k]) { ok = 0; break; }
+        }
+        if (ok) {
+          const int64_t lo = p < 100 ? 0 : p - 100;               /* framer.py:156-159 */
+          const float med = median_f32(in0 + lo, (int)(p - lo));
+          eob = p + 63 * (int64_t)sps;                            /* framer.py:165 */
+          const int64_t off = abs_offset - (H - 1) + p;           /* framer.py:170 */
+          if (ntags < cap) {
+            orec* r = &out[ntags];
+            memset(r, 0, sizeof(*r));
+            r->offset = off; r->peak = in0[p]; r->median = med; r->flags = 2;
+            /* demod.py:75-95 on the stream itself (its in0 has no history) */
+            const int64_t s_off = off - abs_offset;               /* index into x */
+            const double eobd = (double)s_off + 119.0 * sps + sps / 2.0;   /* demod.py:76,80 */
+            if (eobd < (double)n) {                               /* demod.py:82 */
+              const int64_t sob = s_off + 8 * (int64_t)sps;
+              for (int k = 0; k < 112; ++k) {
+                const float b1 = x[sob + (int64_t)k * sps];
+                const float b0 = x[sob + half + (int64_t)k * sps];
+                if (b1 > b0) r->bits[k >> 3] |= (uint8_t)(0x80u >> (k & 7));
+              }
+              r->flags |= 1;
+            }
+          }
+          ++ntags;
+        }
+      }
+      if (cands) {                           /* every matched centre, gated or not (shard-stitch checks) */
+        const float hp = in0[p] / 2.0f;
+        int ok = 1;
+        for (int k = 0; k < 16; ++k) {
+          const int chip = in0[p + (int64_t)k * half] > hp;
+          if (chip != TEMPLATE[k]) { ok = 0; break; }
+        }
+        if (ok) { if (ncand < cand_cap) cands[ncand] = abs_offset - (H - 1) + p; ++ncand; }
+      }
+    }
+    prev = a;
+  }
+  free(in0);
+  if (n_cands) *n_cands = ncand;
+  return ntags <= cap ? ntags : -ntags;
+}
+
+/* complex64 in -> tags, the whole CPU path as the GPU library runs it (baseline timing entry point) */
+int64_t oracle_process_iq(const float* iq, int64_t n, int sps, float thr, int64_t abs_offset, orec* out, int64_t cap) {
+  float* x = (float*)malloc((size_t)(n > 0 ? n : 1) * sizeof(float));
+  if (!x) return -1;
+  oracle_mag2(iq, n, x);
+  int64_t r = oracle_canonical(x, n, sps, thr, abs_offset, out, cap, 0, 0, 0);
+  free(x);
+  return r;
+}

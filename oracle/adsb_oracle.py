@@ -49,8 +49,11 @@ def _median_f32(w):
     """np.median semantics on a float32 window: odd n -> middle, even n -> f32(a+b)/2, NaN if any
     NaN or n == 0 (framer.py:157,159 call np.median directly; this is what the HIP path mirrors)."""
     n = len(w)
-    if n == 0 or np.isnan(w).any():
-        return np.float32(np.nan)
+    if n == 0:
+        # np.median([]) is 0/0: the x86 default NaN, sign bit set (0xFFC00000)
+        return np.array([0xFFC00000], dtype=np.uint32).view(np.float32)[0]
+    if np.isnan(w).any():
+        return np.float32(np.nan)          # a quiet NaN from the data propagates (0x7FC00000)
     s = np.sort(w)
     if n & 1:
         return np.float32(s[n // 2])

@@ -1,0 +1,57 @@
+"""The oracle (NumPy and C) against the golden vectors generated from the REAL reference
+(tools/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from helpers import SCHEDULES, Golden, golden_names, snr_bits, unpack
+from oracle import adsb_oracle as O
+from oracle import c_oracle as C
+
+
+@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("sched", SCHEDULES)
+def test_numpy_oracle_matches_reference_goldens(name, sched):
+    g = Golden(name)
+    o = O.run_stream(g.x, g.fs, g.thr, None if sched == "single" else g.sched(sched))
+    assert np.array_equal(o["tag_offsets"], g.get(sched, "tag_offsets"))
+    assert np.array_equal(o["tag_snr"].view(np.uint32), g.get(sched, "tag_snr_bits"))
+    assert np.array_equal(o["pdu_offsets"], g.get(sched, "pdu_offsets"))
+    assert np.array_equal(o["pdu_bits"], g.pdu_bits(sched))
+    assert np.array_equal(o["pdu_snr"].view(np.uint32), g.get(sched, "pdu_snr_bits"))
+    assert o["final_prev_eob"] == int(g.get(sched, "final_prev_eob"))
+    if sched == "single":
+        assert np.array_equal(o["pdu_conf"].view(np.uint32), g.get(sched, "pdu_conf_bits"))
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_c_oracle_matches_reference_goldens(name):
+    g = Golden(name)
+    r = C.process_iq(g.iq, g.sps, g.thr)
+    assert np.array_equal(r["offset"], g.get("single", "tag_offsets"))
+    assert np.array_equal(snr_bits(r["peak"], r["median"]), g.get("single", "tag_snr_bits"))
+    dem = (r["flags"] & 1) != 0
+    assert np.array_equal(r["offset"][dem], g.get("single", "pdu_offsets"))
+    assert np.array_equal(unpack(r["bits"][dem]), g.pdu_bits("single"))
+
+
+def test_c_oracle_equals_numpy_oracle_on_fresh_synthetic():
+    from gr_adsb_amd import modulator as M
+    for fs, bps, seed in [(2e6, 2000, 1), (6e6, 3000, 2), (20e6, 4000, 3)]:
+        iq = M.synth_iq(1 << 17, fs, bps, seed)
+        sps = int(fs // 1e6)
+        x = O.mag2(iq)
+        o = O.run_stream(x, fs, 0.01)
+        r, cands = C.canonical(x, sps, 0.01, want_cands=True)
+        assert np.array_equal(r["offset"], o["tag_offsets"])
+        assert np.array_equal(r["median"].view(np.uint32), o["tag_median"].view(np.uint32))
+        assert np.array_equal(cands, o["cand_offsets"])
+        assert np.array_equal(O.pack_bits(o["pdu_bits"]), r["bits"][(r["flags"] & 1) != 0])
+
+
+def test_mag2_is_two_rounded_products():
+    rng = np.random.default_rng(0)
+    z = (rng.standard_normal(4096) + 1j * rng.standard_normal(4096)).astype(np.complex64)
+    re = z.real.astype(np.float64)
+    im = z.imag.astype(np.float64)
+    want = (np.float32(re * re).astype(np.float64) + np.float32(im * im).astype(np.float64)).astype(np.float32)
+    assert np.array_equal(O.mag2(z), want)

@@ -1,0 +1,126 @@
+"""The PRODUCT device code (gr_adsb_amd/csrc/adsb_device.h + adsb_plan.h) executed by the CPU SIMT
+emulator (tests/sim/hipsim.h) and checked against the goldens and the oracle.  This is how kernel
+logic is verified in the GPU-less build container; the same checks run on the real GPU through the
+C ABI in test_gpu_parity.py."""
+import warnings
+
+import numpy as np
+import pytest
+
+import simlib
+from helpers import Golden, assert_recs_equal, assert_recs_match_golden, golden_names, unpack
+from gr_adsb_amd import modulator as M
+from oracle import adsb_oracle as O
+from oracle import c_oracle as C
+
+
+@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("mode", [0, 1])
+def test_canonical_matches_goldens(name, mode):
+    g = Golden(name)
+    recs, so = simlib.sim_canonical(mode, g.iq if mode == 0 else g.x, g.fs, g.thr)
+    assert so.overflow == 0
+    assert_recs_match_golden(recs, g)
+    assert np.all((recs["flags"] & 2) != 0)
+
+
+@pytest.mark.parametrize("name", ["g2msps_df17", "g8msps_dense", "g2msps_mixed_lowsnr"])
+@pytest.mark.parametrize("sched", ["fixed4096", "random"])
+def test_framer_work_chunked_matches_goldens(name, sched):
+    g = Golden(name)
+    H = 8 * g.sps
+    buf = np.concatenate([np.zeros(H - 1, np.float32), g.x])
+    fr = simlib.SimFramer(g.fs, g.thr)
+    pos, outs = 0, []
+    for N in g.sched(sched):
+        r, _ = fr.work(buf[pos:pos + N + H - 1], N, pos)
+        outs.append(r)
+        pos += N
+    recs = np.concatenate(outs)
+    assert np.array_equal(recs["offset"], g.get(sched, "tag_offsets"))
+    from helpers import snr_bits
+    assert np.array_equal(snr_bits(recs["peak"], recs["median"]), g.get(sched, "tag_snr_bits"))
+    assert fr.prev_eob.value == int(g.get(sched, "final_prev_eob"))
+    # demod block: k_slice per chunk for the tags inside it
+    pos, got_off, got_bits = 0, [], []
+    offs = g.get(sched, "tag_offsets")
+    for N in g.sched(sched):
+        inside = np.flatnonzero((offs >= pos) & (offs < pos + N))
+        if len(inside):
+            bits, ok, _ = simlib.sim_slice(g.x[pos:pos + N], offs[inside] - pos, g.sps)
+            sel = ok.astype(bool)
+            got_off.append(offs[inside][sel])
+            got_bits.append(unpack(bits[sel]))
+        pos += N
+    assert np.array_equal(np.concatenate(got_off), g.get(sched, "pdu_offsets"))
+    assert np.array_equal(np.concatenate(got_bits), g.pdu_bits(sched))
+
+
+def test_slice_ratio_matches_reference_confidence():
+    g = Golden("g2msps_df17")
+    offs = g.get("single", "pdu_offsets")
+    bits, ok, ratio = simlib.sim_slice(g.x, offs, g.sps)
+    assert ok.all()
+    with np.errstate(all="ignore"):
+        conf = (np.float32(10.0) * np.log10(ratio)).astype(np.float32)
+    assert np.array_equal(conf.view(np.uint32), g.get("single", "pdu_conf_bits"))
+
+
+@pytest.mark.parametrize("fs,bps,shards", [(2e6, 4000, 4), (20e6, 3000, 3)])
+def test_overlapped_shards_stitch_equals_single_call(fs, bps, shards):
+    from gr_adsb_amd.frontend import shard_plan
+    n = 1 << 17
+    iq = M.synth_iq(n, fs, bps, seed=8)
+    sps = int(fs // 1e6)
+    want, cands = C.canonical(O.mag2(iq), sps, 0.01, want_cands=True)
+    got = []
+    for p in shard_plan(n, shards, sps):
+        r, so = simlib.sim_shard(0, iq[p["lo"]:p["hi"]], p["lo"], p["own_lo"], p["own_hi"], n, fs, 0.01)
+        assert (so.flags & 4) == 0
+        got.append(r[(r["flags"] & 12) == 0])
+    c = np.concatenate(got)
+    assert np.array_equal(c["offset"], cands)
+    keep = O.resolve_candidates(c["offset"], sps)
+    assert_recs_equal(c[keep], want, "stitched shards")
+
+
+def test_record_capacity_overflow_is_reported():
+    g = Golden("g2msps_df17")
+    recs, so = simlib.sim_canonical(0, g.iq, g.fs, g.thr, rec_cap=2)
+    assert so.overflow == 1
+
+
+def test_pathological_inputs_match_oracle():
+    fs, sps = 2e6, 2
+    base = O.mag2(M.synth_iq(1 << 15, fs, 5000, seed=21))
+    cases = []
+    x = base.copy(); x[3000:7000] = 0.5; cases.append(("long run", x, 0.01))
+    x = base.copy(); x[2000:22000] = 0.5; cases.append(("run over several tiles", x, 0.01))
+    x = base.copy(); x[:50] = 0.7; x[-40:] = 0.7; cases.append(("starts/ends high", x, 0.01))
+    x = base.copy(); x[[100, 5000, 5001, 20000]] = np.nan; x[[3000, 30000]] = np.inf
+    cases.append(("nan/inf", x, 0.01)); cases.append(("nan/inf thr 0", x, 0.0))
+    cases.append(("thr 0", base, 0.0)); cases.append(("thr < 0", base, -1.0)); cases.append(("thr at noise", base, 0.001))
+    cases.append(("zeros", np.zeros(3000, np.float32), 0.01)); cases.append(("const high", np.full(9000, 0.3, np.float32), 0.01))
+    for n in (1, 15, 16, 17, 239, 240, 241):
+        cases.append(("tiny %d" % n, base[7000:7000 + n].copy(), 0.01))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for what, x, thr in cases:
+            want = C.canonical(x, sps, thr)
+            recs, so = simlib.sim_canonical(1, x, fs, thr)
+            assert_recs_equal(recs, want, what)
+
+
+def test_noise_window_at_stream_start_and_nan_median_bits():
+    """A burst at the very start: the median window is clipped by the zero history (framer.py:156-157)."""
+    fs, sps = 2e6, 2
+    rng = np.random.default_rng(3)
+    bits = M.make_frame(17, rng)
+    env = M.burst_waveform(bits, sps)
+    for lead in (0, 1, 7, 40, 99, 100, 101):
+        x = np.full(600, 1e-4, np.float32)
+        x[lead:lead + len(env)] += 0.5 * env
+        want = C.canonical(x, sps, 0.01)
+        recs, _ = simlib.sim_canonical(1, x, fs, 0.01)
+        assert len(want) == 1
+        assert_recs_equal(recs, want, "lead %d" % lead)

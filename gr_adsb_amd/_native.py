@@ -46,10 +46,20 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    # torch bundles its own HIP runtime (same soname): import it FIRST so that this library binds to the
+    # runtime torch uses; loading ours first and torch afterwards puts two runtimes in one process and
+    # device discovery then fails in the second one.
+    import sys
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+    path = os.environ.get("ADSB_HIP_LIB", LIB_PATH)
+    if not os.path.exists(path):
         raise ImportError("libadsb_hip.so not built: run `python -m gr_adsb_amd.build` (hipcc, gfx950). "
                           "There is no CPU fallback for the ADS-B hot path.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     c = ctypes
     vp, i64, i32, f32 = c.c_void_p, c.c_int64, c.c_int32, c.c_float
     lib.adsb_abi_version.restype = c.c_int

@@ -26,6 +26,7 @@ constexpr int kOwnWords = kTile / 64;    // 64 == one wavefront of word owners
 constexpr unsigned kTemplate = 0x285u;   // chips 0,2,7,9 high (framer.py:50)
 constexpr int kNoise = 100;              // framer.py:31
 constexpr long long kNoIndex = -(1ll << 62);
+static_assert(kFwd == kThreads, "the halo shift moves one float per thread");
 
 enum RecFlags : unsigned {
   kDemod = 1u,     // eob inside the demod input: bits valid (demod.py:82)
@@ -189,59 +190,62 @@ __device__ void emit_record(const Acc& acc, const DetectArgs& a, long long p, Re
   }
 }
 
-// ---- global -> LDS span loader ---------------------------------------------------------------------
-// Loads COUNT samples starting at local index src into sx[dst..], as |IQ|^2 floats; 16-byte loads.
+// ---- global -> register -> LDS tile staging ---------------------------------------------------------
+// A tile body (COUNT samples) is fetched with 16-byte loads into registers (span_issue) and turned into
+// |IQ|^2 floats in LDS later (span_commit), so that the fetch of tile k+1 is in flight while tile k is
+// being processed.  The fast path (whole span inside the buffer) has no per-load branches: all loads of a
+// thread are issued back to back and waited for once.
 template <int MODE, int COUNT>
-__device__ __forceinline__ void load_span(float* sx, int dst, const DetectArgs& a, long long src, int tid) {
-  if (MODE == 0) {
-    constexpr int NV = COUNT / 2;                       // float4 = 2 complex samples
-    constexpr int ITER = (NV + kThreads - 1) / kThreads;
-    float4 q[ITER];
-    const float4* base = reinterpret_cast<const float4*>(a.data);
+struct Span {
+  static constexpr int PER = (MODE == 0) ? 2 : 4;             // samples per float4
+  static constexpr int NV = COUNT / PER;
+  static constexpr int ITER = (NV + kThreads - 1) / kThreads;
+  float4 q[ITER];
+};
+
+template <int MODE, int COUNT>
+__device__ __forceinline__ void span_issue(Span<MODE, COUNT>& sp, const DetectArgs& a, long long src, int tid) {
+  using S = Span<MODE, COUNT>;
+  const float4* base = reinterpret_cast<const float4*>(a.data);
+  if (src + COUNT <= a.n) {                                    // wave-uniform: no bounds checks needed
+    const float4* p = base + src / S::PER + tid;
 #pragma unroll
-    for (int k = 0; k < ITER; ++k) {
-      const int v = tid + k * kThreads;
-      const long long i = src + 2ll * v;
-      q[k].x = q[k].y = q[k].z = q[k].w = 0.0f;
-      if (v < NV) {
-        if (i + 1 < a.n) q[k] = base[i >> 1];
-        else if (i < a.n) { float2 s = reinterpret_cast<const float2*>(a.data)[i]; q[k].x = s.x; q[k].y = s.y; }
-      }
+    for (int k = 0; k < S::ITER; ++k) {
+      if (S::NV % kThreads == 0 || tid + k * kThreads < S::NV) sp.q[k] = p[k * kThreads];
     }
-#pragma unroll
-    for (int k = 0; k < ITER; ++k) {
-      const int v = tid + k * kThreads;
-      if (v < NV) {
-        float2 m;
-        m.x = mag2f(q[k].x, q[k].y);
-        m.y = mag2f(q[k].z, q[k].w);
-        *reinterpret_cast<float2*>(&sx[dst + 2 * v]) = m;
-      }
-    }
-  } else {
-    constexpr int NV = COUNT / 4;                       // float4 = 4 samples
-    constexpr int ITER = (NV + kThreads - 1) / kThreads;
-    float4 q[ITER];
-    const float4* base = reinterpret_cast<const float4*>(a.data);
+  } else {                                                     // ragged end of the buffer (at most one tile per call)
     const float* fb = reinterpret_cast<const float*>(a.data);
 #pragma unroll
-    for (int k = 0; k < ITER; ++k) {
-      const int v = tid + k * kThreads;
-      const long long i = src + 4ll * v;
-      q[k].x = q[k].y = q[k].z = q[k].w = 0.0f;
-      if (v < NV) {
-        if (i + 3 < a.n) q[k] = base[i >> 2];
-        else {
-          if (i < a.n) q[k].x = fb[i];
-          if (i + 1 < a.n) q[k].y = fb[i + 1];
-          if (i + 2 < a.n) q[k].z = fb[i + 2];
-        }
-      }
-    }
+    for (int k = 0; k < S::ITER; ++k) {
+      const long long i = src + (long long)S::PER * (tid + k * kThreads);
+      float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (MODE == 0) {
+        if (i < a.n) { e[0] = fb[2 * i]; e[1] = fb[2 * i + 1]; }
+        if (i + 1 < a.n) { e[2] = fb[2 * i + 2]; e[3] = fb[2 * i + 3]; }
+      } else {
 #pragma unroll
-    for (int k = 0; k < ITER; ++k) {
-      const int v = tid + k * kThreads;
-      if (v < NV) *reinterpret_cast<float4*>(&sx[dst + 4 * v]) = q[k];
+        for (int c = 0; c < 4; ++c) if (i + c < a.n) e[c] = fb[i + c];
+      }
+      sp.q[k].x = e[0]; sp.q[k].y = e[1]; sp.q[k].z = e[2]; sp.q[k].w = e[3];
+    }
+  }
+}
+
+template <int MODE, int COUNT>
+__device__ __forceinline__ void span_commit(const Span<MODE, COUNT>& sp, float* sx, int dst, int tid) {
+  using S = Span<MODE, COUNT>;
+#pragma unroll
+  for (int k = 0; k < S::ITER; ++k) {
+    const int v = tid + k * kThreads;
+    if (S::NV % kThreads == 0 || v < S::NV) {
+      if (MODE == 0) {
+        float2 m;
+        m.x = mag2f(sp.q[k].x, sp.q[k].y);
+        m.y = mag2f(sp.q[k].z, sp.q[k].w);
+        *reinterpret_cast<float2*>(&sx[dst + 2 * v]) = m;
+      } else {
+        *reinterpret_cast<float4*>(&sx[dst + 4 * v]) = sp.q[k];
+      }
     }
   }
 }
@@ -256,7 +260,7 @@ __global__ void __launch_bounds__(kThreads) k_detect(DetectArgs a) {
   __shared__ __attribute__((aligned(16))) float s_x[kWin];
   __shared__ unsigned long long s_mask[kWords];
   __shared__ unsigned short s_list[kTile / 2];
-  __shared__ int s_nrise, s_ncand, s_nrec, s_pred, s_lastp;
+  __shared__ int s_nrise, s_ncand, s_nrec, s_pred, s_lastp, s_lastp2;
   __shared__ unsigned s_flags;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -289,19 +293,20 @@ __global__ void __launch_bounds__(kThreads) k_detect(DetectArgs a) {
   }
   __syncthreads();
 
-  bool first = true;
+  // prologue: forward-halo head of the first tile straight into LDS, body of the first tile into registers
+  Span<MODE, kTile> body;
+  if (c0 < c1) {
+    Span<MODE, kFwd> head;
+    span_issue<MODE, kFwd>(head, a, c0, tid);
+    span_issue<MODE, kTile>(body, a, c0 + kFwd, tid);
+    span_commit<MODE, kFwd>(head, s_x, 0, tid);
+  }
   for (long long t0 = c0; t0 < c1; t0 += kTile) {
-    // -- window [t0, t0+kWin): forward halo of the previous tile becomes the head of this one
-    if (first) {
-      load_span<MODE, kFwd>(s_x, 0, a, t0, tid);
-    } else {
-      const float keep = s_x[kTile + tid];          // kFwd == kThreads
-      __syncthreads();
-      s_x[tid] = keep;
-    }
-    first = false;
-    load_span<MODE, kTile>(s_x, kFwd, a, t0 + kFwd, tid);
-    if (tid == 0) { s_pred = above_at<MODE>(a, t0 - 1) ? 1 : 0; s_lastp = -1; }
+    // -- window [t0, t0+kWin): sx[0..kFwd) already holds the head; commit the body, then start fetching
+    //    the next tile's body so that it is in flight while this tile is processed
+    span_commit<MODE, kTile>(body, s_x, kFwd, tid);
+    if (t0 + kTile < c1) span_issue<MODE, kTile>(body, a, t0 + kTile + kFwd, tid);
+    if (tid == 0) { s_pred = above_at<MODE>(a, t0 - 1) ? 1 : 0; s_lastp = -1; s_lastp2 = -1; }
     __syncthreads();
 
     // -- B1: one ballot per 64-sample word (framer.py:83-84)
@@ -359,7 +364,8 @@ __global__ void __launch_bounds__(kThreads) k_detect(DetectArgs a) {
         const int f = w * 64 + __builtin_ctzll(inv);
         if (t0 + f < a.fall_hi) {
           const int p = (r + f) >> 1;                    // framer.py:113
-          atomicMax(&s_lastp, p);
+          if (i == nr - 1) s_lastp = p;                  // centres increase with i; only the last rise
+          else if (i == nr - 2) s_lastp2 = p;            // of a tile can be left without a fall
           const float hp = __fmul_rn(s_x[p], 0.5f);      // in0[pulse_idx]/2, exact
           unsigned chips = 0;
 #pragma unroll
@@ -427,9 +433,13 @@ __global__ void __launch_bounds__(kThreads) k_detect(DetectArgs a) {
     __syncthreads();
     if (tid == 0) {
       s_nrec = rec_base + nc;
-      if (s_lastp >= 0) lastp_g = t0 + s_lastp;
+      const int lp = s_lastp >= 0 ? s_lastp : s_lastp2;
+      if (lp >= 0) lastp_g = t0 + lp;
     }
-    // (the next iteration's first barrier orders these writes before their next use)
+    // the forward halo of this tile is the head of the next one (kFwd == kThreads)
+    const float keep = s_x[kTile + tid];
+    __syncthreads();
+    s_x[tid] = keep;
   }
   __syncthreads();
   if (tid == 0) {

@@ -1,17 +1,26 @@
-// adsb_device.h -- CDNA4 (gfx950) device code for the ADS-B front end: |IQ|^2 -> threshold/edge ->
-// pulse centre -> 16-chip preamble test -> (peak, noise median, 112-bit PPM slice) per matched centre,
-// then ordering, the re-trigger gate and compaction.  Written for 64-wide wavefronts: the threshold
-// bitmask of a 64-sample word IS one __ballot, rises are found with scalar mask algebra, and per-burst
-// work (median-of-100, 224 PPM gathers) is done by one whole wavefront per burst.
+// adsb_device.h -- CDNA4 (gfx950) device code for the ADS-B front end.
+//
+//   k_detect   streams the IQ once: |IQ|^2 -> threshold bitmask (one __ballot per 64 samples) -> rises by
+//              mask algebra -> pulse centre -> 16-chip preamble test; emits matched centres per workgroup
+//   k_longrun  (rare) pulses longer than the LDS window
+//   k_scan / k_gather / k_resolve / k_count / k_scan2 / k_compact
+//              order the centres, apply the re-trigger gate as parallel chain walks, compact
+//   k_burst    one wavefront per surviving centre: peak, median-of-100 noise, 112-bit PPM slice
+//   k_slice    PPM slice for a caller-supplied tag list (the stand-alone demod block)
+//
+// Written for 64-wide wavefronts: the threshold mask of 64 samples IS a ballot, rises/falls are 64-bit
+// mask algebra, compaction is ballot + prefix-popcount, per-burst work is done by a whole wavefront.
+// Memory-bound integer/compare work: no MFMA anywhere.
 //
 // Behaviour restated from the reference (citations to /root/reference/python/adsb/):
 //   threshold / edges / pairing   framer.py:83-113      preamble test     framer.py:137-147
 //   SNR inputs (peak, median)     framer.py:156-159     re-trigger gate   framer.py:121-123,165
 //   PPM slice                     demod.py:75-95        confidence ratio  demod.py:101
 //
-// This header contains device code only and includes nothing: the product translation unit
-// (adsb_hip.hip) includes <hip/hip_runtime.h> first; tests/sim/sim_driver.cpp includes the test-only
-// SIMT emulator first so the very same kernels can be checked on a machine without a GPU.
+// This header contains device code only and includes nothing.  The includer provides the HIP device
+// environment plus `adsb_wave_sync()` (a wavefront-level execution/LDS ordering point): the product
+// translation unit adsb_hip.hip maps it to __builtin_amdgcn_wave_barrier(); tests/sim/sim_driver.cpp
+// includes the test-only SIMT emulator instead so the very same kernels run on a machine without a GPU.
 #pragma once
 
 namespace adsb {
@@ -22,11 +31,22 @@ constexpr int kTile = 4096;              // samples owned per tile iteration (64
 constexpr int kFwd = 256;                // forward halo kept in LDS behind every tile
 constexpr int kWin = kTile + kFwd;
 constexpr int kWords = kWin / 64;        // 68
-constexpr int kOwnWords = kTile / 64;    // 64 == one wavefront of word owners
+constexpr int kOwnWords = kTile / 64;    // 64
+constexpr int kQuarter = kTile / kWaves; // samples a wavefront stages and owns per tile
+constexpr int kQWords = kQuarter / 64;   // 16
+constexpr int kHeadWords = kFwd / 64;    // 4
 constexpr unsigned kTemplate = 0x285u;   // chips 0,2,7,9 high (framer.py:50)
 constexpr int kNoise = 100;              // framer.py:31
 constexpr long long kNoIndex = -(1ll << 62);
 static_assert(kFwd == kThreads, "the halo shift moves one float per thread");
+static_assert(kQWords == 16, "word owners are lanes 0..15 of each wavefront");
+
+// Tuning aid (tools/kbench.py builds side copies of the library with -DADSB_ABLATE=k to time phases of
+// k_detect in isolation); the shipped library is always built with 0 = nothing skipped.
+#ifndef ADSB_ABLATE
+#define ADSB_ABLATE 0
+#endif
+constexpr int kAblate = ADSB_ABLATE;
 
 enum RecFlags : unsigned {
   kDemod = 1u,     // eob inside the demod input: bits valid (demod.py:82)
@@ -39,17 +59,27 @@ enum RecFlags : unsigned {
 // w2 = bits 0..63 as bytes 0..7 (first bit = MSB of byte 0); w3 = bytes 8..13 | flags<<48.
 struct Rec { unsigned long long w[4]; };
 
+// A matched centre travels between kernels as one 64-bit word: flags<<56 | (local index + kBias).
+constexpr long long kBias = 1ll << 40;
+__device__ __forceinline__ unsigned long long cand_make(long long p, unsigned flags) {
+  return ((unsigned long long)flags << 56) | (unsigned long long)(p + kBias);
+}
+__device__ __forceinline__ long long cand_p(unsigned long long c) {
+  return (long long)(c & 0x00FFFFFFFFFFFFFFull) - kBias;
+}
+__device__ __forceinline__ unsigned cand_flags(unsigned long long c) { return (unsigned)(c >> 56); }
+
 struct LongRise { long long rise; int blk; int slot; };
 
 struct Summary {
-  int n_rec;        // records (matched centres + placeholders) in sorted order
-  int n_kept;       // after gate
-  int overflow;     // some block exceeded rec_cap
+  int n_rec;        // centres (incl. placeholders) in stream order
+  int n_kept;       // survivors (after the gate, or all real centres when the gate is off)
+  int overflow;     // some workgroup exceeded rec_cap
   int long_count;   // entries in the long-rise list
   unsigned flags;   // bit0 any rise, bit1 any fall, bit2 halo exceeded
   int pad_;
   long long lastp;  // largest paired pulse centre (local index) or kNoIndex
-  long long last_kept_p;  // centre (local) of the last kept record or kNoIndex
+  long long last_kept_p;  // local index of the last survivor or kNoIndex
 };
 
 struct DetectArgs {
@@ -66,9 +96,9 @@ struct DetectArgs {
   float prev_in0;        // value compared for the sample before in0[0] (framer.py:84)
   int sps;
   int end_is_call_end;   // 1: pulse still high at fall_hi is discarded (framer.py:102-108); 0: halo error
-  int rec_cap;           // records per workgroup
+  int rec_cap;           // centres per workgroup
   int long_cap;
-  Rec* recs;             // [grid][rec_cap]
+  unsigned long long* cands;  // [grid][rec_cap]
   int* blk_count;        // [grid]
   long long* blk_lastp;  // [grid]
   unsigned* blk_flags;   // [grid]
@@ -108,39 +138,26 @@ __device__ __forceinline__ unsigned long long bit_range(long long lo, long long 
   return m & ~((1ull << lo) - 1ull);
 }
 
-// ---- window accessor: LDS when the sample is inside the tile window, global otherwise -------------
-template <int MODE>
-struct WinAcc {
-  const float* sx;
-  long long t0;
-  const void* data;
-  long long n;
-  __device__ __forceinline__ float get(long long i) const {
-    long long li = i - t0;
-    if (li >= 0 && li < kWin) return sx[li];
-    return xg<MODE>(data, n, i);
-  }
-};
-template <int MODE>
-struct GlobAcc {
-  const void* data;
-  long long n;
-  __device__ __forceinline__ float get(long long i) const { return xg<MODE>(data, n, i); }
-};
+__device__ __forceinline__ int lanes_below(unsigned long long m, int lane) {
+  return __popcll(m & ((1ull << lane) - 1ull));      // prefix popcount (v_mbcnt)
+}
 
 // ---- one wavefront builds one burst record ---------------------------------------------------------
 // peak = x[p]; median of x[max(in0_base, p-100) : p] with np.median semantics (framer.py:156-159);
 // 112 hard bits b1 > b0 at stride sps (demod.py:87-95).  All 64 lanes must be active.
-template <class Acc>
-__device__ void emit_record(const Acc& acc, const DetectArgs& a, long long p, Rec* out, int lane) {
-  const float peak = acc.get(p);
+template <int MODE>
+__device__ void emit_record(const DetectArgs& a, long long p, Rec* out, int lane) {
+  const void* d = a.data;
+  const long long n = a.n;
+  const float peak = xg<MODE>(d, n, p);
   long long wlo = p - kNoise;
   if (wlo < a.in0_base) wlo = a.in0_base;
   const int nwin = (int)(p - wlo);
   const bool val0 = lane < nwin, val1 = lane + 64 < nwin;
-  const float v0 = val0 ? acc.get(wlo + lane) : 0.0f;
-  const float v1 = val1 ? acc.get(wlo + lane + 64) : 0.0f;
+  const float v0 = val0 ? xg<MODE>(d, n, wlo + lane) : 0.0f;
+  const float v1 = val1 ? xg<MODE>(d, n, wlo + lane + 64) : 0.0f;
   const unsigned long long nanm = __ballot((val0 && v0 != v0) || (val1 && v1 != v1));
+  // exact selection by rank counting: rank = #{smaller} + #{equal with lower index}
   int r0 = 0, r1 = 0;
   for (int j = 0; j < nwin; ++j) {
     const float e = __shfl(j < 64 ? v0 : v1, j & 63);
@@ -169,10 +186,10 @@ __device__ void emit_record(const Acc& acc, const DetectArgs& a, long long p, Re
   bool b0 = false, b1 = false;
   if (dem) {
     const long long s0 = p + 8ll * sps + (long long)lane * sps;           // demod.py:75,87
-    b0 = acc.get(s0) > acc.get(s0 + half);                                // demod.py:91,95
+    b0 = xg<MODE>(d, n, s0) > xg<MODE>(d, n, s0 + half);                  // demod.py:91,95
     if (lane < 48) {
       const long long s1 = s0 + 64ll * sps;
-      b1 = acc.get(s1) > acc.get(s1 + half);
+      b1 = xg<MODE>(d, n, s1) > xg<MODE>(d, n, s1 + half);
     }
   }
   const unsigned long long ma = __ballot(b0), mb = __ballot(b1);
@@ -190,61 +207,97 @@ __device__ void emit_record(const Acc& acc, const DetectArgs& a, long long p, Re
   }
 }
 
-// ---- global -> register -> LDS tile staging ---------------------------------------------------------
-// A tile body (COUNT samples) is fetched with 16-byte loads into registers (span_issue) and turned into
-// |IQ|^2 floats in LDS later (span_commit), so that the fetch of tile k+1 is in flight while tile k is
-// being processed.  The fast path (whole span inside the buffer) has no per-load branches: all loads of a
-// thread are issued back to back and waited for once.
+// ---- global -> register -> LDS staging of one wavefront's share of a span ----------------------------
+// A span of COUNT samples is split into kWaves contiguous shares; each wavefront fetches its share with
+// 16-byte loads (1 KiB contiguous per wave instruction) into registers (span_issue) and later turns it
+// into |IQ|^2 floats in LDS AND into the natural-order threshold bitmask words of those samples
+// (span_commit) -- so the fetch of tile k+1 is in flight while tile k is processed, and the threshold
+// masks cost no LDS re-read.  The fast path (whole span inside the buffer) has no per-load branches.
 template <int MODE, int COUNT>
 struct Span {
   static constexpr int PER = (MODE == 0) ? 2 : 4;             // samples per float4
-  static constexpr int NV = COUNT / PER;
-  static constexpr int ITER = (NV + kThreads - 1) / kThreads;
+  static constexpr int SHARE = COUNT / kWaves;                // samples per wavefront
+  static constexpr int GROUP = 64 * PER;                      // samples per wave-wide load
+  static constexpr int ITER = (SHARE + GROUP - 1) / GROUP;    // (a partial last group only for the head span)
+  static constexpr int LANES = (SHARE < GROUP) ? SHARE / PER : 64;   // active lanes when SHARE < GROUP
   float4 q[ITER];
 };
 
 template <int MODE, int COUNT>
-__device__ __forceinline__ void span_issue(Span<MODE, COUNT>& sp, const DetectArgs& a, long long src, int tid) {
+__device__ __forceinline__ void span_issue(Span<MODE, COUNT>& sp, const DetectArgs& a, long long src, int wave, int lane) {
   using S = Span<MODE, COUNT>;
-  const float4* base = reinterpret_cast<const float4*>(a.data);
+  const long long wsrc = src + (long long)wave * S::SHARE;
   if (src + COUNT <= a.n) {                                    // wave-uniform: no bounds checks needed
-    const float4* p = base + src / S::PER + tid;
+    const float4* p = reinterpret_cast<const float4*>(a.data) + wsrc / S::PER + lane;
 #pragma unroll
     for (int k = 0; k < S::ITER; ++k) {
-      if (S::NV % kThreads == 0 || tid + k * kThreads < S::NV) sp.q[k] = p[k * kThreads];
+      if (S::LANES == 64 || lane < S::LANES) sp.q[k] = p[k * 64];
+      else { sp.q[k].x = sp.q[k].y = sp.q[k].z = sp.q[k].w = 0.0f; }
     }
   } else {                                                     // ragged end of the buffer (at most one tile per call)
     const float* fb = reinterpret_cast<const float*>(a.data);
 #pragma unroll
     for (int k = 0; k < S::ITER; ++k) {
-      const long long i = src + (long long)S::PER * (tid + k * kThreads);
+      const long long i = wsrc + (long long)k * S::GROUP + (long long)S::PER * lane;
       float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (MODE == 0) {
-        if (i < a.n) { e[0] = fb[2 * i]; e[1] = fb[2 * i + 1]; }
-        if (i + 1 < a.n) { e[2] = fb[2 * i + 2]; e[3] = fb[2 * i + 3]; }
-      } else {
+      if (S::LANES == 64 || lane < S::LANES) {
+        if (MODE == 0) {
+          if (i < a.n) { e[0] = fb[2 * i]; e[1] = fb[2 * i + 1]; }
+          if (i + 1 < a.n) { e[2] = fb[2 * i + 2]; e[3] = fb[2 * i + 3]; }
+        } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) if (i + c < a.n) e[c] = fb[i + c];
+          for (int c = 0; c < 4; ++c) if (i + c < a.n) e[c] = fb[i + c];
+        }
       }
       sp.q[k].x = e[0]; sp.q[k].y = e[1]; sp.q[k].z = e[2]; sp.q[k].w = e[3];
     }
   }
 }
 
+// dst = LDS sample index of the span's first sample (multiple of 64).  Every lane of the wavefront
+// must call this (ballots); a wavefront whose share is one 64-sample word (the head span) uses only
+// its low lanes for data and writes one mask word.
 template <int MODE, int COUNT>
-__device__ __forceinline__ void span_commit(const Span<MODE, COUNT>& sp, float* sx, int dst, int tid) {
+__device__ __forceinline__ void span_commit(const Span<MODE, COUNT>& sp, float* sx, unsigned long long* smask,
+                                            int dst, float thr, int wave, int lane) {
   using S = Span<MODE, COUNT>;
+  const int wdst = dst + wave * S::SHARE;
+  const bool act = (S::LANES == 64) || lane < S::LANES;
 #pragma unroll
   for (int k = 0; k < S::ITER; ++k) {
-    const int v = tid + k * kThreads;
-    if (S::NV % kThreads == 0 || v < S::NV) {
-      if (MODE == 0) {
-        float2 m;
-        m.x = mag2f(sp.q[k].x, sp.q[k].y);
-        m.y = mag2f(sp.q[k].z, sp.q[k].w);
-        *reinterpret_cast<float2*>(&sx[dst + 2 * v]) = m;
-      } else {
-        *reinterpret_cast<float4*>(&sx[dst + 4 * v]) = sp.q[k];
+    const int g = wdst + k * S::GROUP;                        // first LDS sample of this wave-wide group
+    if (MODE == 0) {
+      float2 m;
+      m.x = mag2f(sp.q[k].x, sp.q[k].y);
+      m.y = mag2f(sp.q[k].z, sp.q[k].w);
+      if (act) *reinterpret_cast<float2*>(&sx[g + 2 * lane]) = m;
+      if (kAblate < 3) {
+        // lane l holds samples 2l, 2l+1: E/O masks -> natural-order words (framer.py:83-84)
+        const unsigned long long E = __ballot(act && m.x >= thr), O = __ballot(act && m.y >= thr);
+        const unsigned long long sel = (lane & 1) ? O : E;
+        const unsigned long long w0 = __ballot((sel >> (lane >> 1)) & 1ull);
+        if (lane == 0) smask[g >> 6] = w0;
+        if (S::SHARE >= 128) {
+          const unsigned long long w1 = __ballot((sel >> (32 + (lane >> 1))) & 1ull);
+          if (lane == 0) smask[(g >> 6) + 1] = w1;
+        }
+      }
+    } else {
+      if (act) *reinterpret_cast<float4*>(&sx[g + 4 * lane]) = sp.q[k];
+      if (kAblate < 3) {
+        const unsigned long long A = __ballot(act && sp.q[k].x >= thr), B = __ballot(act && sp.q[k].y >= thr);
+        const unsigned long long C = __ballot(act && sp.q[k].z >= thr), D = __ballot(act && sp.q[k].w >= thr);
+        const int c = lane & 3;
+        const unsigned long long sel = (c == 0) ? A : (c == 1) ? B : (c == 2) ? C : D;
+        const int sh = lane >> 2;
+        const unsigned long long w0 = __ballot((sel >> sh) & 1ull);
+        if (lane == 0) smask[g >> 6] = w0;
+        if (S::SHARE >= 256) {
+          const unsigned long long w1 = __ballot((sel >> (16 + sh)) & 1ull);
+          const unsigned long long w2 = __ballot((sel >> (32 + sh)) & 1ull);
+          const unsigned long long w3 = __ballot((sel >> (48 + sh)) & 1ull);
+          if (lane == 0) { smask[(g >> 6) + 1] = w1; smask[(g >> 6) + 2] = w2; smask[(g >> 6) + 3] = w3; }
+        }
       }
     }
   }
@@ -252,15 +305,17 @@ __device__ __forceinline__ void span_commit(const Span<MODE, COUNT>& sp, float* 
 
 // ---- k_detect: the streaming kernel ----------------------------------------------------------------
 // One workgroup walks a contiguous chunk of the stream tile by tile with a sliding LDS window of
-// kTile + kFwd |IQ|^2 floats (the forward halo of one tile is the head of the next, so every sample
-// is fetched from HBM once).  Records are appended to the workgroup's own slice of `recs` in stream
-// order; ordering across workgroups is by workgroup index (k_scan / k_gather).
+// kTile + kFwd |IQ|^2 floats plus their threshold bitmask (the forward halo of one tile is the head of the
+// next, so every sample is fetched from HBM once).  Each wavefront stages and owns a quarter of the
+// tile; three barriers per tile.  Matched centres are appended to the workgroup's own slice of `cands`
+// in stream order; ordering across workgroups is by workgroup index (k_scan / k_gather).
 template <int MODE>
 __global__ void __launch_bounds__(kThreads) k_detect(DetectArgs a) {
   __shared__ __attribute__((aligned(16))) float s_x[kWin];
   __shared__ unsigned long long s_mask[kWords];
-  __shared__ unsigned short s_list[kTile / 2];
-  __shared__ int s_nrise, s_ncand, s_nrec, s_pred, s_lastp, s_lastp2;
+  __shared__ unsigned short s_rise[kWaves][kQuarter / 2];
+  __shared__ int s_nmatch[kWaves], s_wlastp[kWaves], s_wflags[kWaves];
+  __shared__ int s_nrec, s_pred;
   __shared__ unsigned s_flags;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -270,147 +325,144 @@ __global__ void __launch_bounds__(kThreads) k_detect(DetectArgs a) {
   const int half = a.sps >> 1;
   long long lastp_g = kNoIndex;
 
-  if (tid == 0) { s_nrec = 0; s_flags = 0u; }
-  __syncthreads();
-
-  // virtual rise in the zero history in front of a fresh stream: only possible when 0 >= thr
-  if (blockIdx.x == 0 && wave == 0 && a.scan_lo < 0) {
-    const bool vr = (0.0f >= a.thr) && !(a.prev_in0 >= a.thr);
-    if (vr) {
-      if (lane == 0) {
-        s_flags |= 1u;
-        const int slot = s_nrec;
-        if (slot < a.rec_cap) {
-          Rec r; r.w[0] = (unsigned long long)a.scan_lo; r.w[1] = 0; r.w[2] = 0;
-          r.w[3] = (unsigned long long)(kPending | kNoMatch) << 48;
-          a.recs[(long long)blockIdx.x * a.rec_cap + slot] = r;
-          const int li = atomicAdd(a.long_count, 1);
-          if (li < a.long_cap) { LongRise e; e.rise = a.scan_lo; e.blk = 0; e.slot = slot; a.longlist[li] = e; }
-        }
-        s_nrec = slot + 1;
+  if (tid == 0) {
+    s_nrec = 0; s_flags = 0u; s_pred = above_at<MODE>(a, c0 - 1) ? 1 : 0;
+    // virtual rise in the zero history in front of a fresh stream: only possible when 0 >= thr
+    if (blockIdx.x == 0 && a.scan_lo < 0 && (0.0f >= a.thr) && !(a.prev_in0 >= a.thr)) {
+      s_flags |= 1u;
+      if (0 < a.rec_cap) {
+        a.cands[0] = cand_make(a.scan_lo, kPending | kNoMatch);
+        const int li = atomicAdd(a.long_count, 1);
+        if (li < a.long_cap) { LongRise e; e.rise = a.scan_lo; e.blk = 0; e.slot = 0; a.longlist[li] = e; }
       }
+      s_nrec = 1;
     }
   }
-  __syncthreads();
 
-  // prologue: forward-halo head of the first tile straight into LDS, body of the first tile into registers
+  // prologue: head of the first tile straight into LDS (with its mask words), first body into registers
   Span<MODE, kTile> body;
   if (c0 < c1) {
     Span<MODE, kFwd> head;
-    span_issue<MODE, kFwd>(head, a, c0, tid);
-    span_issue<MODE, kTile>(body, a, c0 + kFwd, tid);
-    span_commit<MODE, kFwd>(head, s_x, 0, tid);
+    span_issue<MODE, kFwd>(head, a, c0, wave, lane);
+    span_issue<MODE, kTile>(body, a, c0 + kFwd, wave, lane);
+    span_commit<MODE, kFwd>(head, s_x, s_mask, 0, a.thr, wave, lane);
   }
+
   for (long long t0 = c0; t0 < c1; t0 += kTile) {
-    // -- window [t0, t0+kWin): sx[0..kFwd) already holds the head; commit the body, then start fetching
-    //    the next tile's body so that it is in flight while this tile is processed
-    span_commit<MODE, kTile>(body, s_x, kFwd, tid);
-    if (t0 + kTile < c1) span_issue<MODE, kTile>(body, a, t0 + kTile + kFwd, tid);
-    if (tid == 0) { s_pred = above_at<MODE>(a, t0 - 1) ? 1 : 0; s_lastp = -1; s_lastp2 = -1; }
+    // -- A: window [t0, t0+kWin).  s_x[0..kFwd) and mask words 0..3 already hold the head; commit the body
+    //       (floats + mask words 4..67), then start fetching the next body so it is in flight below
+    if (kAblate < 4) span_commit<MODE, kTile>(body, s_x, s_mask, kFwd, a.thr, wave, lane);
+    else { float acc = 0.0f; for (int k = 0; k < Span<MODE, kTile>::ITER; ++k) acc += body.q[k].x + body.q[k].w; if (acc == 123.456f) s_x[tid] = acc; }
+    if (t0 + kTile < c1) span_issue<MODE, kTile>(body, a, t0 + kTile + kFwd, wave, lane);
     __syncthreads();
 
-    // -- B1: one ballot per 64-sample word (framer.py:83-84)
-    for (int w = wave; w < kWords; w += kWaves) {
-      const float v = s_x[w * 64 + lane];
-      const unsigned long long m = __ballot(v >= a.thr);
-      if (lane == 0) s_mask[w] = m;
-    }
-    __syncthreads();
-
-    // -- B2: rises / falls by mask algebra, ordered rise list (framer.py:91-93)
-    if (wave == 0) {
-      const unsigned long long M = s_mask[lane];
-      const unsigned long long pb = (lane > 0) ? (s_mask[lane - 1] >> 63) : (unsigned long long)s_pred;
+    // -- B: every wavefront handles the rises of its own 16 mask words, no cross-wave sync inside
+    int nm = 0;
+    if (kAblate < 3) {
+      // B.1 rises / falls by mask algebra (framer.py:91-93); lanes 0..15 own one word each
+      const int word = wave * kQWords + (lane & 15);
+      const unsigned long long M = s_mask[word];
+      const unsigned long long pb = (word > 0) ? (s_mask[word - 1] >> 63) : (unsigned long long)s_pred;
       const unsigned long long sh = (M << 1) | pb;
-      const long long wbase = t0 + 64ll * lane;
-      const unsigned long long own = bit_range(a.scan_lo - wbase, a.scan_hi - wbase);
+      const long long wbase = t0 + 64ll * word;
+      const unsigned long long own = (lane < 16) ? bit_range(a.scan_lo - wbase, a.scan_hi - wbase) : 0ull;
       unsigned long long R = M & ~sh & own;
       const unsigned long long Fm = ~M & sh & own;
       const unsigned long long anyr = __ballot(R != 0ull), anyf = __ballot(Fm != 0ull);
       const int cnt = __popcll(R);
       int incl = cnt;
-      for (int d = 1; d < 64; d <<= 1) {
+      for (int d = 1; d < 16; d <<= 1) {
         const int t = __shfl_up(incl, (unsigned)d);
         if (lane >= d) incl += t;
       }
       int pos = incl - cnt;
-      const int total = __shfl(incl, 63);
+      const int nr = __shfl(incl, 15);
       while (R) {
         const int b = __builtin_ctzll(R);
         R &= R - 1ull;
-        s_list[pos++] = (unsigned short)(64 * lane + b);
+        s_rise[wave][pos++] = (unsigned short)(64 * word + b);
       }
-      if (lane == 0) {
-        s_nrise = total;
-        s_flags |= (anyr ? 1u : 0u) | (anyf ? 2u : 0u);
-      }
-    }
-    __syncthreads();
+      if (lane == 0) s_wflags[wave] = (anyr ? 1 : 0) | (anyf ? 2 : 0);
+      adsb_wave_sync();
 
-    // -- B3: per rise: fall, centre, 16-chip test (framer.py:113,137-147)
-    const int nr = s_nrise;
-    for (int i = tid; i < nr; i += kThreads) {
-      const int r = s_list[i];
-      int w = r >> 6;
-      const int b = r & 63;
-      unsigned long long inv = ~s_mask[w];
-      inv = (b == 63) ? 0ull : (inv & (~0ull << (b + 1)));
-      while (inv == 0ull && ++w < kWords) inv = ~s_mask[w];
-      unsigned short res = 0;
-      if (inv == 0ull) {
-        if (t0 + kWin < a.fall_hi) res = 0xFFFFu;        // pulse longer than the window: k_longrun
-        else if (!a.end_is_call_end) atomicOr(&s_flags, 4u);
-      } else {
-        const int f = w * 64 + __builtin_ctzll(inv);
-        if (t0 + f < a.fall_hi) {
-          const int p = (r + f) >> 1;                    // framer.py:113
-          if (i == nr - 1) s_lastp = p;                  // centres increase with i; only the last rise
-          else if (i == nr - 2) s_lastp2 = p;            // of a tile can be left without a fall
-          const float hp = __fmul_rn(s_x[p], 0.5f);      // in0[pulse_idx]/2, exact
-          unsigned chips = 0;
+      // B.2 per rise: fall, centre, 16-chip test (framer.py:113,137-147)
+      int lp = -1, lp2 = -1, hflag = 0;
+      const int nre = (kAblate >= 2) ? 0 : nr;
+      for (int i = lane; i < nre; i += 64) {
+        const int r = s_rise[wave][i];
+        int w = r >> 6;
+        const int b = r & 63;
+        unsigned long long inv = ~s_mask[w];
+        inv = (b == 63) ? 0ull : (inv & (~0ull << (b + 1)));
+        while (inv == 0ull && ++w < kWords) inv = ~s_mask[w];
+        unsigned short res = 0;
+        if (inv == 0ull) {
+          if (t0 + kWin < a.fall_hi) res = 0xFFFFu;        // pulse longer than the window: k_longrun
+          else if (!a.end_is_call_end) hflag = 4;
+        } else {
+          const int f = w * 64 + __builtin_ctzll(inv);
+          if (t0 + f < a.fall_hi) {
+            const int p = (r + f) >> 1;                    // framer.py:113
+            if (i == nr - 1) lp = p;                       // centres increase with i; only the last rise of
+            else if (i == nr - 2) lp2 = p;                 // a tile can be left without a fall
+            const float hp = __fmul_rn(s_x[p], 0.5f);      // in0[pulse_idx]/2, exact
+            unsigned chips = 0;
 #pragma unroll
-          for (int k = 0; k < 16; ++k) {
-            const int idx = p + k * half;
-            const float v = (idx < kWin) ? s_x[idx] : xg<MODE>(a.data, a.n, t0 + idx);
-            chips |= (v > hp ? 1u : 0u) << k;
+            for (int k = 0; k < 16; ++k) {
+              const int idx = p + k * half;
+              const float v = (idx < kWin) ? s_x[idx] : xg<MODE>(a.data, a.n, t0 + idx);
+              chips |= (v > hp ? 1u : 0u) << k;
+            }
+            if (chips == kTemplate) res = (unsigned short)(0x8000u | (unsigned)p);
+          } else if (!a.end_is_call_end) {
+            hflag = 4;
           }
-          if (chips == kTemplate) res = (unsigned short)(0x8000u | (unsigned)p);
-        } else if (!a.end_is_call_end) {
-          atomicOr(&s_flags, 4u);
+        }
+        s_rise[wave][i] = res;
+      }
+      // last paired centre of this wavefront's quarter and halo flag -> one LDS word per wavefront
+      {
+        const unsigned long long m1 = __ballot(lp >= 0), m2 = __ballot(lp2 >= 0), mh = __ballot(hflag != 0);
+        const int v1 = __shfl(lp, m1 ? __builtin_ctzll(m1) : 0);
+        const int v2 = __shfl(lp2, m2 ? __builtin_ctzll(m2) : 0);
+        if (lane == 0) {
+          s_wlastp[wave] = m1 ? v1 : (m2 ? v2 : -1);
+          if (mh) s_wflags[wave] |= 4;
         }
       }
-      s_list[i] = res;
-    }
-    __syncthreads();
+      adsb_wave_sync();
 
-    // -- B4: ordered in-place compaction of the matched centres
-    if (wave == 0) {
-      int nc = 0;
-      for (int base = 0; base < nr; base += 64) {
+      // B.3 ordered in-place compaction of this wavefront's matched centres
+      for (int base = 0; base < nre; base += 64) {
         const int i = base + lane;
-        const unsigned short e = (i < nr) ? s_list[i] : (unsigned short)0;
+        const unsigned short e = (i < nre) ? s_rise[wave][i] : (unsigned short)0;
         const unsigned long long mb = __ballot(e != 0);
-        const int pos = nc + __popcll(mb & ((1ull << lane) - 1ull));
-        if (e) s_list[pos] = e;
-        nc += __popcll(mb);
+        if (e) s_rise[wave][nm + lanes_below(mb, lane)] = e;
+        nm += __popcll(mb);
       }
-      if (lane == 0) s_ncand = nc;
+      if (lane == 0) s_nmatch[wave] = nm;
+    } else {
+      if (lane == 0) { s_nmatch[wave] = 0; s_wlastp[wave] = -1; s_wflags[wave] = 0; }
     }
     __syncthreads();
 
-    // -- C: one wavefront per matched centre builds the record
-    const int nc = s_ncand;
+    // -- C: append the matched centres (wave order == stream order) to this workgroup's list
+    int pre = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      const int c = s_nmatch[w];
+      if (w < wave) pre += c;
+      tot += c;
+    }
     const int rec_base = s_nrec;
-    WinAcc<MODE> acc{s_x, t0, a.data, a.n};
-    for (int m = wave; m < nc; m += kWaves) {
-      const unsigned short e = s_list[m];
-      const int slot = rec_base + m;
-      if (slot < a.rec_cap) {
-        Rec* out = a.recs + (long long)blockIdx.x * a.rec_cap + slot;
-        if (e == 0xFFFFu) {
-          if (lane == 0) {
-            // the long pulse is the last rise of its tile; its rise index is the last set bit's
-            // successor search start: recover it from the masks (last rise in the owned words)
+    if (kAblate < 1) {
+      for (int i = lane; i < nm; i += 64) {
+        const unsigned short e = s_rise[wave][i];
+        const int slot = rec_base + pre + i;
+        if (slot < a.rec_cap) {
+          unsigned long long* out = a.cands + (long long)blockIdx.x * a.rec_cap + slot;
+          if (e == 0xFFFFu) {
+            // the long pulse is the last rise of its tile: recover its index from the masks
             long long rg = kNoIndex;
             for (int w2 = kOwnWords - 1; w2 >= 0 && rg == kNoIndex; --w2) {
               const unsigned long long M = s_mask[w2];
@@ -419,27 +471,33 @@ __global__ void __launch_bounds__(kThreads) k_detect(DetectArgs a) {
               const unsigned long long R = M & ~((M << 1) | pb) & bit_range(a.scan_lo - wb, a.scan_hi - wb);
               if (R) rg = wb + (63 - __builtin_clzll(R));
             }
-            Rec r; r.w[0] = (unsigned long long)rg; r.w[1] = 0; r.w[2] = 0;
-            r.w[3] = (unsigned long long)(kPending | kNoMatch) << 48;
-            *out = r;
+            *out = cand_make(rg, kPending | kNoMatch);
             const int li = atomicAdd(a.long_count, 1);
             if (li < a.long_cap) { LongRise le; le.rise = rg; le.blk = (int)blockIdx.x; le.slot = slot; a.longlist[li] = le; }
+          } else {
+            *out = cand_make(t0 + (long long)(e & 0x7FFFu), 0u);
           }
-        } else {
-          emit_record(acc, a, t0 + (long long)(e & 0x7FFFu), out, lane);
         }
       }
     }
-    __syncthreads();
-    if (tid == 0) {
-      s_nrec = rec_base + nc;
-      const int lp = s_lastp >= 0 ? s_lastp : s_lastp2;
-      if (lp >= 0) lastp_g = t0 + lp;
-    }
-    // the forward halo of this tile is the head of the next one (kFwd == kThreads)
+    // what the next tile inherits: the forward halo (floats + mask words) and the last threshold bit
     const float keep = s_x[kTile + tid];
+    const unsigned long long keepm = (tid < kHeadWords) ? s_mask[kOwnWords + tid] : 0ull;
+    int wl = -1, keepp = 0; unsigned wf = 0;
+    if (tid == 0) {
+      keepp = (int)(s_mask[kOwnWords - 1] >> 63);
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) { if (s_wlastp[w] >= 0) wl = s_wlastp[w]; wf |= (unsigned)s_wflags[w]; }
+    }
     __syncthreads();
     s_x[tid] = keep;
+    if (tid < kHeadWords) s_mask[tid] = keepm;
+    if (tid == 0) {
+      s_pred = keepp;
+      s_nrec = rec_base + ((kAblate < 1) ? tot : 0);
+      s_flags |= wf;
+      if (wl >= 0) lastp_g = t0 + wl;
+    }
   }
   __syncthreads();
   if (tid == 0) {
@@ -451,7 +509,7 @@ __global__ void __launch_bounds__(kThreads) k_detect(DetectArgs a) {
 
 // ---- k_longrun: pulses whose run leaves the LDS window (or starts in the zero history) -------------
 // One workgroup per entry scans forward cooperatively for the fall, then wave 0 finishes the pulse
-// with global-memory taps.  Rare (CW / overload); correctness path, not a fast path.
+// with global-memory taps and overwrites the placeholder.  Rare (CW / overload): correctness path.
 template <int MODE>
 __global__ void __launch_bounds__(kThreads) k_longrun(DetectArgs a, int n_entries) {
   __shared__ unsigned long long s_found;   // fall index relative to rise+1
@@ -477,7 +535,7 @@ __global__ void __launch_bounds__(kThreads) k_longrun(DetectArgs a, int n_entrie
     }
     __syncthreads();
     const long long f = (s_found == none) ? limit : start + (long long)s_found;
-    Rec* out = a.recs + (long long)le.blk * a.rec_cap + le.slot;
+    unsigned long long* out = a.cands + (long long)le.blk * a.rec_cap + le.slot;
     if (wave == 0) {
       if (f < limit) {
         const long long p = (le.rise + f) >> 1;            // floor, also for negative indices
@@ -485,17 +543,10 @@ __global__ void __launch_bounds__(kThreads) k_longrun(DetectArgs a, int n_entrie
         const float hp = __fmul_rn(xg<MODE>(a.data, a.n, p), 0.5f);
         const float v = (lane < 16) ? xg<MODE>(a.data, a.n, p + (long long)lane * (a.sps >> 1)) : 0.0f;
         const unsigned long long cm = __ballot(lane < 16 && v > hp);
-        if ((unsigned)cm == kTemplate) {
-          GlobAcc<MODE> acc{a.data, a.n};
-          emit_record(acc, a, p, out, lane);
-        } else if (lane == 0) {
-          out->w[3] = (unsigned long long)kNoMatch << 48;
-        }
-      } else {
-        if (lane == 0) {
-          out->w[3] = (unsigned long long)kNoMatch << 48;
-          if (!a.end_is_call_end) atomicOr(a.blk_flags + le.blk, 4u);
-        }
+        if (lane == 0) *out = ((unsigned)cm == kTemplate) ? cand_make(p, 0u) : cand_make(p, kNoMatch);
+      } else if (lane == 0) {
+        *out = cand_make(le.rise, kNoMatch);
+        if (!a.end_is_call_end) atomicOr(a.blk_flags + le.blk, 4u);
       }
     }
     __syncthreads();
@@ -547,53 +598,48 @@ __global__ void __launch_bounds__(kThreads) k_scan(const int* blk_count, const l
 }
 
 // ---- k_gather: per-workgroup slices -> one list in stream order ------------------------------------
-__global__ void __launch_bounds__(kThreads) k_gather(const Rec* recs, const int* blk_count, const int* blk_off,
-                                                     int nblk, int rec_cap, Rec* sorted) {
+__global__ void __launch_bounds__(kThreads) k_gather(const unsigned long long* cands, const int* blk_count,
+                                                     const int* blk_off, int nblk, int rec_cap,
+                                                     unsigned long long* sorted) {
   for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
     int c = blk_count[b];
     if (c > rec_cap) c = rec_cap;
     const int off = blk_off[b];
-    for (int j = threadIdx.x; j < c; j += kThreads) sorted[off + j] = recs[(long long)b * rec_cap + j];
+    for (int j = threadIdx.x; j < c; j += kThreads) sorted[off + j] = cands[(long long)b * rec_cap + j];
   }
 }
 
 // ---- k_resolve: the re-trigger gate (framer.py:121-123,165) as parallel chain walks -----------------
 // Sequentially: accept a matched centre p iff p > eob, then eob = p + 63*sps.  A centre more than
 // 63*sps past its predecessor is accepted whatever happened before it, so it starts an independent
-// chain; each chain head walks its own (short) chain.  Records flagged kNoMatch are skipped.
-__device__ __forceinline__ long long rec_p(const Rec& r) { return (long long)r.w[0]; }
-__device__ __forceinline__ unsigned rec_flags(const Rec& r) { return (unsigned)(r.w[3] >> 48); }
-
-__global__ void __launch_bounds__(kThreads) k_resolve(Rec* sorted, const Summary* sum, long long gate,
-                                                      long long prev_eob_stream, int* seg_count) {
-  // gate = 63*sps; prev_eob_stream = carried eob expressed as a stream offset (or very negative)
-  __shared__ int s_cnt[kWaves];
+// chain; each chain head walks its own (short) chain.  Words flagged kNoMatch are skipped.
+__global__ void __launch_bounds__(kThreads) k_resolve(unsigned long long* sorted, const Summary* sum, long long gate,
+                                                      long long prev_eob) {
+  // gate = 63*sps; prev_eob = carried eob as a local index (or very negative)
   const int n = sum->n_rec;
   const int nseg = (n + kThreads - 1) / kThreads;
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const int i = seg * kThreads + threadIdx.x;
-    bool head = false;
-    if (i < n && !(rec_flags(sorted[i]) & kNoMatch)) {
-      const long long p = rec_p(sorted[i]);
+    if (i < n && !(cand_flags(sorted[i]) & kNoMatch)) {
+      const long long p = cand_p(sorted[i]);
       int j = i - 1;
-      while (j >= 0 && (rec_flags(sorted[j]) & kNoMatch)) --j;
-      if (j < 0) head = true;                         // first real centre: walks from the carried eob
-      else head = (p - rec_p(sorted[j]) > gate) && (p > prev_eob_stream);
+      while (j >= 0 && (cand_flags(sorted[j]) & kNoMatch)) --j;
+      const bool head = (j < 0) || ((p - cand_p(sorted[j]) > gate) && (p > prev_eob));
       if (head) {
-        long long eob = (j < 0) ? prev_eob_stream : (p - 1);   // a head with a predecessor is always accepted
+        long long eob = (j < 0) ? prev_eob : (p - 1);   // a head with a predecessor is always accepted
         int k = i;
         while (k < n) {
-          const unsigned fl = rec_flags(sorted[k]);
-          if (!(fl & kNoMatch)) {
-            const long long pk = rec_p(sorted[k]);
+          const unsigned long long ck = sorted[k];
+          if (!(cand_flags(ck) & kNoMatch)) {
+            const long long pk = cand_p(ck);
             if (k != i) {
               // stop at the next head: it owns the rest
               int jj = k - 1;
-              while (jj >= 0 && (rec_flags(sorted[jj]) & kNoMatch)) --jj;
-              if (jj >= 0 && pk - rec_p(sorted[jj]) > gate && pk > prev_eob_stream) break;
+              while (jj >= 0 && (cand_flags(sorted[jj]) & kNoMatch)) --jj;
+              if (jj >= 0 && pk - cand_p(sorted[jj]) > gate && pk > prev_eob) break;
             }
             if (pk > eob) {
-              sorted[k].w[3] |= (unsigned long long)kKept << 48;
+              sorted[k] = ck | ((unsigned long long)kKept << 56);
               eob = pk + gate;
             }
           }
@@ -602,18 +648,20 @@ __global__ void __launch_bounds__(kThreads) k_resolve(Rec* sorted, const Summary
       }
     }
   }
-  (void)s_cnt; (void)seg_count;
 }
 
-// ---- k_count / k_compact: kept records -> dense output ---------------------------------------------
-__global__ void __launch_bounds__(kThreads) k_count(const Rec* sorted, const Summary* sum, int* seg_count) {
+// ---- k_count / k_scan2 / k_compact: survivors -> dense list ------------------------------------------
+// A word survives when (flags & fmask) == fwant: gate on -> (kKept, kKept); gate off (shards) -> every
+// real centre: (kNoMatch | kPending, 0).
+__global__ void __launch_bounds__(kThreads) k_count(const unsigned long long* sorted, const Summary* sum,
+                                                    unsigned fmask, unsigned fwant, int* seg_count) {
   __shared__ int s_c[kWaves];
   const int n = sum->n_rec;
   const int nseg = (n + kThreads - 1) / kThreads;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const int i = seg * kThreads + threadIdx.x;
-    const bool kept = i < n && (rec_flags(sorted[i]) & kKept);
+    const bool kept = i < n && (cand_flags(sorted[i]) & fmask) == fwant;
     const unsigned long long m = __ballot(kept);
     if (lane == 0) s_c[wave] = __popcll(m);
     __syncthreads();
@@ -622,8 +670,8 @@ __global__ void __launch_bounds__(kThreads) k_count(const Rec* sorted, const Sum
   }
 }
 
-__global__ void __launch_bounds__(kThreads) k_scan2(int* seg_count, Summary* sum, const Rec* sorted) {
-  // exclusive scan of seg_count in place (single workgroup) + totals
+__global__ void __launch_bounds__(kThreads) k_scan2(int* seg_count, Summary* sum) {
+  // exclusive scan of seg_count in place (single workgroup) + total
   __shared__ int s_part[kThreads];
   const int n = sum->n_rec;
   const int nseg = (n + kThreads - 1) / kThreads;
@@ -639,37 +687,49 @@ __global__ void __launch_bounds__(kThreads) k_scan2(int* seg_count, Summary* sum
     int run = 0;
     for (int t = 0; t < kThreads; ++t) { const int c = s_part[t]; s_part[t] = run; run += c; }
     sum->n_kept = run;
-    long long lk = kNoIndex;
-    for (int i = n - 1; i >= 0; --i) {
-      if (rec_flags(sorted[i]) & kKept) { lk = rec_p(sorted[i]); break; }
-    }
-    sum->last_kept_p = lk;
   }
   __syncthreads();
   int run = s_part[tid];
   for (int b = b0; b < b1; ++b) { const int c = seg_count[b]; seg_count[b] = run; run += c; }
 }
 
-__global__ void __launch_bounds__(kThreads) k_compact(const Rec* sorted, const Summary* sum, const int* seg_off,
-                                                      Rec* out, int out_cap) {
+__global__ void __launch_bounds__(kThreads) k_compact(const unsigned long long* sorted, Summary* sum,
+                                                      const int* seg_off, unsigned fmask, unsigned fwant,
+                                                      unsigned long long* kept, int out_cap) {
   __shared__ int s_c[kWaves];
   const int n = sum->n_rec;
   const int nseg = (n + kThreads - 1) / kThreads;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const int i = seg * kThreads + threadIdx.x;
-    Rec r;
-    r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
-    if (i < n) r = sorted[i];
-    const bool kept = i < n && (rec_flags(r) & kKept);
-    const unsigned long long m = __ballot(kept);
+    const unsigned long long c = (i < n) ? sorted[i] : 0ull;
+    const bool k = i < n && (cand_flags(c) & fmask) == fwant;
+    const unsigned long long m = __ballot(k);
     if (lane == 0) s_c[wave] = __popcll(m);
     __syncthreads();
     int off = seg_off[seg];
     for (int w = 0; w < wave; ++w) off += s_c[w];
-    off += __popcll(m & ((1ull << lane) - 1ull));
-    if (kept && off < out_cap) out[off] = r;
+    off += lanes_below(m, lane);
+    if (k && off < out_cap) {
+      kept[off] = c;
+      if (off == sum->n_kept - 1) sum->last_kept_p = cand_p(c);
+    }
     __syncthreads();
+  }
+}
+
+// ---- k_burst: one wavefront per surviving centre -> the 32-byte burst record -------------------------
+template <int MODE>
+__global__ void __launch_bounds__(kThreads) k_burst(DetectArgs a, const unsigned long long* kept, const Summary* sum,
+                                                    unsigned orflags, Rec* out, int out_cap) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = (int)((blockIdx.x * (unsigned)kThreads + threadIdx.x) >> 6);
+  const int nwave = (int)((gridDim.x * (unsigned)kThreads) >> 6);
+  int n = sum->n_kept;
+  if (n > out_cap) n = out_cap;
+  for (int t = wave_g; t < n; t += nwave) {
+    emit_record<MODE>(a, cand_p(kept[t]), out + t, lane);
+    if (lane == 0 && orflags) out[t].w[3] |= (unsigned long long)orflags << 48;
   }
 }
 

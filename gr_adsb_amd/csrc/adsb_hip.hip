@@ -1,6 +1,6 @@
 // adsb_hip.hip -- host side of libadsb_hip.so (C ABI in include/adsb_hip.h) for gfx950.
 // Owns device memory, pinned staging and the launch sequence
-//   k_detect -> k_scan -> k_gather -> k_resolve -> k_count -> k_scan2 -> k_compact  (+ k_longrun when needed)
+//   k_detect -> k_scan -> k_gather -> k_resolve -> k_count -> k_scan2 -> k_compact -> k_burst  (+ k_longrun when needed)
 // There is deliberately no CPU implementation of the path in this library.
 #include <hip/hip_runtime.h>
 
@@ -10,6 +10,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+
+// wavefront-level ordering point used by adsb_device.h: LDS traffic of one wavefront is executed in
+// program order by the hardware, this only stops the compiler from moving LDS accesses across it
+__device__ __forceinline__ void adsb_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 #include "adsb_device.h"
 #include "adsb_plan.h"
@@ -40,7 +48,7 @@ struct adsb_ctx {
   // framer state (framer.py:54,57)
   FramerState st;
   // device buffers
-  DevBuf d_in, d_recs, d_blk_count, d_blk_lastp, d_blk_flags, d_blk_off, d_long, d_misc, d_sorted, d_seg, d_out,
+  DevBuf d_in, d_cands, d_kept, d_blk_count, d_blk_lastp, d_blk_flags, d_blk_off, d_long, d_misc, d_sorted, d_seg, d_out,
       d_tags, d_bits, d_ok, d_ratio;
   int rec_cap_shift = 0;  // rec_cap multiplier (grows on overflow)
   // pinned host
@@ -103,6 +111,11 @@ void launch_detect(adsb_ctx* c, const DetectArgs& a, int grid) {
   hipLaunchKernelGGL((k_detect<MODE>), dim3(grid), dim3(kThreads), 0, c->stream, a);
 }
 template <int MODE>
+void launch_burst(adsb_ctx* c, const DetectArgs& a, const unsigned long long* kept, const Summary* sum, unsigned orflags,
+                  Rec* out, int cap) {
+  hipLaunchKernelGGL((k_burst<MODE>), dim3(c->n_cu * 8), dim3(kThreads), 0, c->stream, a, kept, sum, orflags, out, cap);
+}
+template <int MODE>
 void launch_longrun(adsb_ctx* c, const DetectArgs& a, int n) {
   int g = n < 256 ? n : 256;
   hipLaunchKernelGGL((k_longrun<MODE>), dim3(g), dim3(kThreads), 0, c->stream, a, n);
@@ -130,8 +143,9 @@ int run_pipeline(adsb_ctx* c, const Plan& pl, Summary* sum, int32_t* n_res) {
     const int long_cap = grid + 1;  // at most one long pulse per tile that ends a chunk... bounded by tiles
     const long long long_cap_ll = ntiles + 1;
     int rcx;
-    if ((rcx = ensure(c, c->d_recs, (size_t)tot * sizeof(Rec)))) return rcx;
-    if ((rcx = ensure(c, c->d_sorted, (size_t)tot * sizeof(Rec)))) return rcx;
+    if ((rcx = ensure(c, c->d_cands, (size_t)tot * 8))) return rcx;
+    if ((rcx = ensure(c, c->d_sorted, (size_t)tot * 8))) return rcx;
+    if ((rcx = ensure(c, c->d_kept, (size_t)tot * 8))) return rcx;
     if ((rcx = ensure(c, c->d_out, (size_t)tot * sizeof(Rec)))) return rcx;
     if ((rcx = ensure(c, c->d_seg, (size_t)(tot / kThreads + 2) * sizeof(int)))) return rcx;
     if ((rcx = ensure(c, c->d_blk_count, (size_t)grid * sizeof(int)))) return rcx;
@@ -147,7 +161,7 @@ int run_pipeline(adsb_ctx* c, const Plan& pl, Summary* sum, int32_t* n_res) {
     a.data = pl.d_data; a.n = pl.n; a.in0_base = pl.in0_base; a.scan_lo = pl.scan_lo; a.scan_hi = pl.scan_hi;
     a.fall_hi = pl.fall_hi; a.dem_hi = pl.dem_hi; a.origin = pl.origin; a.chunk = chunk; a.thr = c->thr;
     a.prev_in0 = pl.prev_in0; a.sps = c->sps; a.end_is_call_end = pl.end_is_call_end; a.rec_cap = rec_cap;
-    a.long_cap = (int)long_cap_ll; a.recs = (Rec*)c->d_recs.p; a.blk_count = (int*)c->d_blk_count.p;
+    a.long_cap = (int)long_cap_ll; a.cands = (unsigned long long*)c->d_cands.p; a.blk_count = (int*)c->d_blk_count.p;
     a.blk_lastp = (long long*)c->d_blk_lastp.p; a.blk_flags = (unsigned*)c->d_blk_flags.p;
     a.longlist = (LongRise*)c->d_long.p; a.long_count = &misc->long_count; a.long_lastp = &misc->long_lastp;
 
@@ -164,19 +178,24 @@ int run_pipeline(adsb_ctx* c, const Plan& pl, Summary* sum, int32_t* n_res) {
                          (const int*)a.long_count, (const unsigned long long*)a.long_lastp, (int*)c->d_blk_off.p,
                          &misc->sum);
       int gg = grid < 1024 ? grid : 1024;
-      hipLaunchKernelGGL(k_gather, dim3(gg), dim3(kThreads), 0, c->stream, (const Rec*)a.recs,
-                         (const int*)a.blk_count, (const int*)c->d_blk_off.p, grid, rec_cap, (Rec*)c->d_sorted.p);
+      unsigned long long* sorted = (unsigned long long*)c->d_sorted.p;
+      unsigned long long* kept = (unsigned long long*)c->d_kept.p;
+      hipLaunchKernelGGL(k_gather, dim3(gg), dim3(kThreads), 0, c->stream, (const unsigned long long*)a.cands,
+                         (const int*)a.blk_count, (const int*)c->d_blk_off.p, grid, rec_cap, sorted);
+      const int ag = 512;
+      unsigned fmask = kNoMatch | kPending, fwant = 0u, orflags = 0u;
       if (pl.gate) {
-        const int ag = 512;
-        hipLaunchKernelGGL(k_resolve, dim3(ag), dim3(kThreads), 0, c->stream, (Rec*)c->d_sorted.p,
-                           (const Summary*)&misc->sum, (long long)63 * c->sps, pl.prev_eob_stream, (int*)c->d_seg.p);
-        hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, c->stream, (const Rec*)c->d_sorted.p,
-                           (const Summary*)&misc->sum, (int*)c->d_seg.p);
-        hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kThreads), 0, c->stream, (int*)c->d_seg.p, &misc->sum,
-                           (const Rec*)c->d_sorted.p);
-        hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, c->stream, (const Rec*)c->d_sorted.p,
-                           (const Summary*)&misc->sum, (const int*)c->d_seg.p, (Rec*)c->d_out.p, (int)tot);
+        hipLaunchKernelGGL(k_resolve, dim3(ag), dim3(kThreads), 0, c->stream, sorted, (const Summary*)&misc->sum,
+                           (long long)63 * c->sps, pl.prev_eob_stream - pl.origin);
+        fmask = kKept; fwant = kKept; orflags = kKept;
       }
+      hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, c->stream, (const unsigned long long*)sorted,
+                         (const Summary*)&misc->sum, fmask, fwant, (int*)c->d_seg.p);
+      hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kThreads), 0, c->stream, (int*)c->d_seg.p, &misc->sum);
+      hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, c->stream, (const unsigned long long*)sorted,
+                         &misc->sum, (const int*)c->d_seg.p, fmask, fwant, kept, (int)tot);
+      if (pl.mode == 0) launch_burst<0>(c, a, kept, &misc->sum, orflags, (Rec*)c->d_out.p, (int)tot);
+      else launch_burst<1>(c, a, kept, &misc->sum, orflags, (Rec*)c->d_out.p, (int)tot);
       HIPCHK(c, hipMemcpyAsync(c->h_sum, &misc->sum, sizeof(Summary), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       HIPCHK(c, hipGetLastError());
@@ -206,11 +225,11 @@ int run_pipeline(adsb_ctx* c, const Plan& pl, Summary* sum, int32_t* n_res) {
       continue;
     }
     *sum = *c->h_sum;
-    const int nres = pl.gate ? sum->n_kept : sum->n_rec;
+    const int nres = sum->n_kept;
     int rcx2;
     if ((rcx2 = ensure_pinned(c, c->h_out, c->h_out_cap, (size_t)(nres > 0 ? nres : 1) * sizeof(Rec)))) return rcx2;
     if (nres > 0) {
-      const void* src = pl.gate ? c->d_out.p : c->d_sorted.p;
+      const void* src = c->d_out.p;
       HIPCHK(c, hipMemcpyAsync(c->h_out, src, (size_t)nres * sizeof(Rec), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -295,7 +314,7 @@ void adsb_destroy(adsb_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  DevBuf* bufs[] = {&c->d_in, &c->d_recs, &c->d_blk_count, &c->d_blk_lastp, &c->d_blk_flags, &c->d_blk_off, &c->d_long,
+  DevBuf* bufs[] = {&c->d_in, &c->d_cands, &c->d_kept, &c->d_blk_count, &c->d_blk_lastp, &c->d_blk_flags, &c->d_blk_off, &c->d_long,
                     &c->d_misc, &c->d_sorted, &c->d_seg, &c->d_out, &c->d_tags, &c->d_bits, &c->d_ok, &c->d_ratio};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (c->h_sum) (void)hipHostFree(c->h_sum);
@@ -382,7 +401,7 @@ int adsb_framer_work(adsb_ctx* c, const float* in0, int64_t n_in0, int64_t N, in
   if (rc) return rc;
   // cross-call state, exactly as framer.py:87,121-123,165,177-179 (in0 index == local index here)
   framer_state_update(c->st, in0[N - 1], N, c->sps, s.flags, s.lastp, kNoIndex, nres,
-                      nres > 0 ? s.last_kept_p - pl.origin : 0);
+                      nres > 0 ? s.last_kept_p : 0);
   return deliver(c, nres, tags, cap, n_out);
 }
 
@@ -441,7 +460,6 @@ int adsb_shard_device(adsb_ctx* c, int fmt, const void* d_data, int64_t n, int64
   int w = 0;
   for (int i = 0; i < nres; ++i) {
     const unsigned fl = (unsigned)(r[i].w[3] >> 48);
-    if (fl & (kNoMatch | kPending)) continue;
     const long long off = (long long)r[i].w[0];
     const long long eob = off + 119ll * c->sps + c->sps / 2;
     if (!(fl & kDemod) && eob < stream_len) return fail(c, -EOVERFLOW, "internal: demod flag");

@@ -182,6 +182,12 @@ template <class T> inline T __shfl_up(T v, unsigned d) {
   return r;
 }
 
+// wavefront-level ordering point required by adsb_device.h (device: compiler fence + wave_barrier)
+inline void adsb_wave_sync() {
+  hipsim::Block* b = hipsim::cur_block();
+  hipsim::wave_sync(b->waves[b->cur >> 6]);
+}
+
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline unsigned long long __brevll(unsigned long long v) {
   unsigned long long r = 0;

@@ -39,7 +39,8 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   float* dbuf = (float*)aligned_alloc(64, ((nfl * 4 + 63) / 64 + 1) * 64);
   memcpy(dbuf, data, nfl * 4);
 
-  std::vector<Rec> recs(tot), sorted(tot), outv(tot);
+  std::vector<unsigned long long> cands(tot), sorted(tot), kept(tot);
+  std::vector<Rec> outv(tot);
   std::vector<int> blk_count(grid), blk_off(grid), seg(tot / kThreads + 2);
   std::vector<long long> blk_lastp(grid);
   std::vector<unsigned> blk_flags(grid);
@@ -52,7 +53,7 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   a.data = dbuf; a.n = n; a.in0_base = in0_base; a.scan_lo = scan_lo; a.scan_hi = scan_hi; a.fall_hi = fall_hi;
   a.dem_hi = dem_hi; a.origin = origin; a.chunk = chunk; a.thr = thr; a.prev_in0 = prev_in0; a.sps = sps;
   a.end_is_call_end = end_is_call_end; a.rec_cap = rec_cap; a.long_cap = (int)(ntiles + 1);
-  a.recs = recs.data(); a.blk_count = blk_count.data(); a.blk_lastp = blk_lastp.data();
+  a.cands = cands.data(); a.blk_count = blk_count.data(); a.blk_lastp = blk_lastp.data();
   a.blk_flags = blk_flags.data(); a.longlist = longlist.data(); a.long_count = &long_count;
   a.long_lastp = &long_lastp;
 
@@ -64,16 +65,23 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     hipsim::launch(k_scan, 1, kThreads, (const int*)blk_count.data(), (const long long*)blk_lastp.data(),
                    (const unsigned*)blk_flags.data(), grid, rec_cap, (const int*)&long_count,
                    (const unsigned long long*)&long_lastp, blk_off.data(), &sum);
-    hipsim::launch(k_gather, grid < 8 ? grid : 8, kThreads, (const Rec*)recs.data(), (const int*)blk_count.data(),
-                   (const int*)blk_off.data(), grid, rec_cap, sorted.data());
+    hipsim::launch(k_gather, grid < 8 ? grid : 8, kThreads, (const unsigned long long*)cands.data(),
+                   (const int*)blk_count.data(), (const int*)blk_off.data(), grid, rec_cap, sorted.data());
+    unsigned fmask = kNoMatch | kPending, fwant = 0u, orflags = 0u;
     if (gate) {
       hipsim::launch(k_resolve, 3, kThreads, sorted.data(), (const Summary*)&sum, (long long)63 * sps,
-                     prev_eob_stream, seg.data());
-      hipsim::launch(k_count, 3, kThreads, (const Rec*)sorted.data(), (const Summary*)&sum, seg.data());
-      hipsim::launch(k_scan2, 1, kThreads, seg.data(), &sum, (const Rec*)sorted.data());
-      hipsim::launch(k_compact, 3, kThreads, (const Rec*)sorted.data(), (const Summary*)&sum, (const int*)seg.data(),
-                     outv.data(), (int)tot);
+                     prev_eob_stream - origin);
+      fmask = kKept; fwant = kKept; orflags = kKept;
     }
+    hipsim::launch(k_count, 3, kThreads, (const unsigned long long*)sorted.data(), (const Summary*)&sum, fmask, fwant,
+                   seg.data());
+    hipsim::launch(k_scan2, 1, kThreads, seg.data(), &sum);
+    hipsim::launch(k_compact, 3, kThreads, (const unsigned long long*)sorted.data(), &sum, (const int*)seg.data(),
+                   fmask, fwant, kept.data(), (int)tot);
+    if (mode == 0) hipsim::launch(k_burst<0>, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum,
+                                  orflags, outv.data(), (int)tot);
+    else hipsim::launch(k_burst<1>, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum,
+                        orflags, outv.data(), (int)tot);
     if (sum.long_count > 0 && !did_long && !sum.overflow) {
       did_long = true;
       int nl = sum.long_count;
@@ -85,8 +93,8 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   }
   so->n_rec = sum.n_rec; so->n_kept = sum.n_kept; so->overflow = sum.overflow; so->long_count = sum.long_count;
   so->flags = sum.flags; so->lastp = sum.lastp; so->last_kept = sum.last_kept_p;
-  const int nres = gate ? sum.n_kept : sum.n_rec;
-  const Rec* src = gate ? outv.data() : sorted.data();
+  const int nres = sum.n_kept;
+  const Rec* src = outv.data();
   free(dbuf);
   if (nres > out_cap) return -1;
   memcpy(out_recs, src, (size_t)nres * sizeof(Rec));
@@ -112,7 +120,7 @@ int sim_framer_work(const float* in0, long long n_in0, long long N, long long ni
                    p.end_is_call_end, p.prev_eob_stream, 1, grid_max, 0, out, out_cap, so);
   if (rc) return rc;
   framer_state_update(st, in0[N - 1], N, sps, so->flags, so->lastp, kNoIndex, so->n_kept,
-                      so->n_kept > 0 ? so->last_kept - p.origin : 0);
+                      so->n_kept > 0 ? so->last_kept : 0);
   *prev_in0 = st.prev_in0; *prev_eob = st.prev_eob;
   return 0;
 }

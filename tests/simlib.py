@@ -59,8 +59,7 @@ def sim_run(mode, data, sps, thr, in0_base, scan_lo, scan_hi, fall_hi, dem_hi, o
                        c.c_longlong(prev_eob_stream), c.c_int(1 if gate else 0), c.c_int(grid_max), c.c_int(rec_cap),
                        out.ctypes.data_as(c.c_void_p), c.c_int(cap), c.byref(so))
     assert rc == 0
-    nres = so.n_kept if gate else so.n_rec
-    return out[:nres].copy(), so
+    return out[:so.n_kept].copy(), so
 
 
 def sim_canonical(mode, data, fs, thr, abs_offset=0, **kw):
@@ -76,7 +75,7 @@ def _call(fn, args, cap, gate=True):
     so = SimOut()
     rc = fn(*args, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(cap), ctypes.byref(so))
     assert rc == 0, rc
-    return out[:(so.n_kept if gate else so.n_rec)].copy(), so
+    return out[:so.n_kept].copy(), so
 
 
 class SimFramer:

@@ -145,54 +145,67 @@ __device__ __forceinline__ int lanes_below(unsigned long long m, int lane) {
 // ---- one wavefront builds one burst record ---------------------------------------------------------
 // peak = x[p]; median of x[max(in0_base, p-100) : p] with np.median semantics (framer.py:156-159);
 // 112 hard bits b1 > b0 at stride sps (demod.py:87-95).  All 64 lanes must be active.
+// The median is an exact MSB-first radix select over order-preserving integer keys (two window
+// samples per lane, counts by ballot + popcount): 32 wave-uniform steps instead of a sort.
+__device__ __forceinline__ unsigned f32_key(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);        // monotone: key(a) < key(b) <=> a < b
+}
+__device__ __forceinline__ float key_f32(unsigned k) {
+  return __builtin_bit_cast(float, k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
 template <int MODE>
 __device__ void emit_record(const DetectArgs& a, long long p, Rec* out, int lane) {
   const void* d = a.data;
   const long long n = a.n;
-  const float peak = xg<MODE>(d, n, p);
+  const int sps = a.sps, half = sps >> 1;
   long long wlo = p - kNoise;
   if (wlo < a.in0_base) wlo = a.in0_base;
   const int nwin = (int)(p - wlo);
   const bool val0 = lane < nwin, val1 = lane + 64 < nwin;
+  const bool dem = p + 119ll * sps + half < a.dem_hi;   // demod.py:76,82 (sps even)
+  const bool dem1 = dem && lane < 48;
+  const long long s0 = p + 8ll * sps + (long long)lane * sps;             // demod.py:75,87
+  const long long s1 = s0 + 64ll * sps;
+  // every global read of this burst is issued before any of them is used
+  const float peak = xg<MODE>(d, n, p);
   const float v0 = val0 ? xg<MODE>(d, n, wlo + lane) : 0.0f;
   const float v1 = val1 ? xg<MODE>(d, n, wlo + lane + 64) : 0.0f;
+  const float x1 = dem ? xg<MODE>(d, n, s0) : 0.0f;
+  const float x0 = dem ? xg<MODE>(d, n, s0 + half) : 0.0f;                // demod.py:91
+  const float y1 = dem1 ? xg<MODE>(d, n, s1) : 0.0f;
+  const float y0 = dem1 ? xg<MODE>(d, n, s1 + half) : 0.0f;
+
   const unsigned long long nanm = __ballot((val0 && v0 != v0) || (val1 && v1 != v1));
-  // exact selection by rank counting: rank = #{smaller} + #{equal with lower index}
-  int r0 = 0, r1 = 0;
-  for (int j = 0; j < nwin; ++j) {
-    const float e = __shfl(j < 64 ? v0 : v1, j & 63);
-    r0 += (e < v0 || (e == v0 && j < lane)) ? 1 : 0;
-    r1 += (e < v1 || (e == v1 && j < lane + 64)) ? 1 : 0;
+  const unsigned k0 = val0 ? f32_key(v0) : 0xFFFFFFFFu;      // lanes outside the window sort last
+  const unsigned k1 = val1 ? f32_key(v1) : 0xFFFFFFFFu;
+  int k = (nwin - 1) >> 1;                                   // lower middle (the middle for odd n)
+  unsigned prefix = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned want = prefix >> bit;                     // bucket members whose current bit is 0
+    const int c0 = __popcll(__ballot((k0 >> bit) == want)) + __popcll(__ballot((k1 >> bit) == want));
+    if (k >= c0) { k -= c0; prefix |= 1u << bit; }
   }
+  const unsigned A = prefix;                                 // key of the lower middle
   float med;
-  {
-    const int khi = nwin >> 1;               // upper middle (the middle for odd n)
-    const int klo = (nwin & 1) ? khi : khi - 1;
-    const unsigned long long h0 = __ballot(val0 && r0 == khi), h1 = __ballot(val1 && r1 == khi);
-    const unsigned long long l0 = __ballot(val0 && r0 == klo), l1 = __ballot(val1 && r1 == klo);
-    const float sa = __shfl(v0, h0 ? __builtin_ctzll(h0) : 0);
-    const float sb = __shfl(v1, h1 ? __builtin_ctzll(h1) : 0);
-    const float sc = __shfl(v0, l0 ? __builtin_ctzll(l0) : 0);
-    const float sd = __shfl(v1, l1 ? __builtin_ctzll(l1) : 0);
-    const float hi = h0 ? sa : sb;
-    const float lo = l0 ? sc : sd;
-    if (nwin == 0) med = __builtin_bit_cast(float, 0xFFC00000u);   // np.median([]) == 0/0: default NaN, sign set
-    else if (nanm) med = __builtin_bit_cast(float, 0x7FC00000u);    // a NaN in the window propagates
-    else if (nwin & 1) med = hi;
-    else med = __fmul_rn(__fadd_rn(lo, hi), 0.5f);     // f32(a+b)/2
-  }
-  const int sps = a.sps, half = sps >> 1;
-  const bool dem = p + 119ll * sps + half < a.dem_hi;   // demod.py:76,82 (sps even)
-  bool b0 = false, b1 = false;
-  if (dem) {
-    const long long s0 = p + 8ll * sps + (long long)lane * sps;           // demod.py:75,87
-    b0 = xg<MODE>(d, n, s0) > xg<MODE>(d, n, s0 + half);                  // demod.py:91,95
-    if (lane < 48) {
-      const long long s1 = s0 + 64ll * sps;
-      b1 = xg<MODE>(d, n, s1) > xg<MODE>(d, n, s1 + half);
+  if (nwin == 0) med = __builtin_bit_cast(float, 0xFFC00000u);       // np.median([]) == 0/0: default NaN, sign set
+  else if (nanm) med = __builtin_bit_cast(float, 0x7FC00000u);        // a NaN in the window propagates
+  else if (nwin & 1) med = key_f32(A);
+  else {
+    // upper middle: A again if it occurs often enough, else the smallest key above A
+    const int cle = __popcll(__ballot(k0 <= A)) + __popcll(__ballot(k1 <= A));
+    unsigned m = 0xFFFFFFFFu;
+    if (k0 > A) m = k0;
+    if (k1 > A && k1 < m) m = k1;
+    for (int d2 = 32; d2 >= 1; d2 >>= 1) {
+      const unsigned o = __shfl_xor(m, d2);
+      if (o < m) m = o;
     }
+    const unsigned B = (cle >= ((nwin - 1) >> 1) + 2) ? A : m;
+    med = __fmul_rn(__fadd_rn(key_f32(A), key_f32(B)), 0.5f);          // f32(a+b)/2
   }
-  const unsigned long long ma = __ballot(b0), mb = __ballot(b1);
+  const unsigned long long ma = __ballot(dem && x1 > x0), mb = __ballot(dem1 && y1 > y0);   // demod.py:95
   if (lane == 0) {
     const unsigned long long ra = __builtin_bswap64(__brevll(ma));
     const unsigned long long rb = __builtin_bswap64(__brevll(mb)) & 0xFFFFFFFFFFFFull;
@@ -407,11 +420,16 @@ __global__ void __launch_bounds__(kThreads) k_detect(DetectArgs a) {
             else if (i == nr - 2) lp2 = p;                 // a tile can be left without a fall
             const float hp = __fmul_rn(s_x[p], 0.5f);      // in0[pulse_idx]/2, exact
             unsigned chips = 0;
+            if (p + 15 * half < kWin) {                    // all 16 taps inside the LDS window
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-              const int idx = p + k * half;
-              const float v = (idx < kWin) ? s_x[idx] : xg<MODE>(a.data, a.n, t0 + idx);
-              chips |= (v > hp ? 1u : 0u) << k;
+              for (int k = 0; k < 16; ++k) chips |= (s_x[p + k * half] > hp ? 1u : 0u) << k;
+            } else {                                       // rare: taps past the window come from global memory
+#pragma unroll 1
+              for (int k = 0; k < 16; ++k) {
+                const int idx = p + k * half;
+                const float v = (idx < kWin) ? s_x[idx] : xg<MODE>(a.data, a.n, t0 + idx);
+                chips |= (v > hp ? 1u : 0u) << k;
+              }
             }
             if (chips == kTemplate) res = (unsigned short)(0x8000u | (unsigned)p);
           } else if (!a.end_is_call_end) {

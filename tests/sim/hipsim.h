@@ -182,6 +182,11 @@ template <class T> inline T __shfl_up(T v, unsigned d) {
   return r;
 }
 
+template <class T> inline T __shfl_xor(T v, int mask) {
+  int lane = hipsim::cur_block()->cur & 63;
+  return hipsim_shfl_idx(v, lane ^ mask);
+}
+
 // wavefront-level ordering point required by adsb_device.h (device: compiler fence + wave_barrier)
 inline void adsb_wave_sync() {
   hipsim::Block* b = hipsim::cur_block();

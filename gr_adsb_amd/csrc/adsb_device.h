@@ -18,8 +18,9 @@
 //   PPM slice                     demod.py:75-95        confidence ratio  demod.py:101
 //
 // This header contains device code only and includes nothing.  The includer provides the HIP device
-// environment plus `adsb_wave_sync()` (a wavefront-level execution/LDS ordering point): the product
-// translation unit adsb_hip.hip maps it to __builtin_amdgcn_wave_barrier(); tests/sim/sim_driver.cpp
+// environment plus `adsb_wave_sync()` (a wavefront-level execution/LDS ordering point) and `adsb_uniform(int)`
+// (marks a wavefront-uniform value so it lives in a scalar register): the product translation unit adsb_hip.hip
+// maps them to __builtin_amdgcn_wave_barrier() / __builtin_amdgcn_readfirstlane(); tests/sim/sim_driver.cpp
 // includes the test-only SIMT emulator instead so the very same kernels run on a machine without a GPU.
 #pragma once
 
@@ -47,6 +48,11 @@ static_assert(kQWords == 16, "word owners are lanes 0..15 of each wavefront");
 #define ADSB_ABLATE 0
 #endif
 constexpr int kAblate = ADSB_ABLATE;
+// k_detect is latency bound per workgroup: 5 resident workgroups per CU (<= 96 VGPRs, no spills) measured
+// 15-20 % faster than 4; 6 would need spills to scratch.
+#ifndef ADSB_MIN_WAVES
+#define ADSB_MIN_WAVES 5
+#endif
 
 enum RecFlags : unsigned {
   kDemod = 1u,     // eob inside the demod input: bits valid (demod.py:82)
@@ -236,34 +242,35 @@ struct Span {
   float4 q[ITER];
 };
 
+// Returns false (wave- and block-uniform) when the span is not entirely inside the buffer: the caller
+// then stages it with span_fill_ragged instead (at most one tile per call ends ragged).
 template <int MODE, int COUNT>
-__device__ __forceinline__ void span_issue(Span<MODE, COUNT>& sp, const DetectArgs& a, long long src, int wave, int lane) {
+__device__ __forceinline__ bool span_issue(Span<MODE, COUNT>& sp, const DetectArgs& a, long long src, int wave, int lane) {
   using S = Span<MODE, COUNT>;
+  if (src + COUNT > a.n) return false;
+  // scalar base + 32-bit lane offset: one address VGPR for all loads of the span
   const long long wsrc = src + (long long)wave * S::SHARE;
-  if (src + COUNT <= a.n) {                                    // wave-uniform: no bounds checks needed
-    const float4* p = reinterpret_cast<const float4*>(a.data) + wsrc / S::PER + lane;
+  const char* ub = reinterpret_cast<const char*>(a.data) + wsrc * (16 / S::PER);
+  const unsigned lo = (unsigned)lane * 16u;
 #pragma unroll
-    for (int k = 0; k < S::ITER; ++k) {
-      if (S::LANES == 64 || lane < S::LANES) sp.q[k] = p[k * 64];
-      else { sp.q[k].x = sp.q[k].y = sp.q[k].z = sp.q[k].w = 0.0f; }
-    }
-  } else {                                                     // ragged end of the buffer (at most one tile per call)
-    const float* fb = reinterpret_cast<const float*>(a.data);
-#pragma unroll
-    for (int k = 0; k < S::ITER; ++k) {
-      const long long i = wsrc + (long long)k * S::GROUP + (long long)S::PER * lane;
-      float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (S::LANES == 64 || lane < S::LANES) {
-        if (MODE == 0) {
-          if (i < a.n) { e[0] = fb[2 * i]; e[1] = fb[2 * i + 1]; }
-          if (i + 1 < a.n) { e[2] = fb[2 * i + 2]; e[3] = fb[2 * i + 3]; }
-        } else {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) if (i + c < a.n) e[c] = fb[i + c];
-        }
-      }
-      sp.q[k].x = e[0]; sp.q[k].y = e[1]; sp.q[k].z = e[2]; sp.q[k].w = e[3];
-    }
+  for (int k = 0; k < S::ITER; ++k) {
+    if (S::LANES == 64 || lane < S::LANES) sp.q[k] = *reinterpret_cast<const float4*>(ub + (k * 1024 + lo));
+    else { sp.q[k].x = sp.q[k].y = sp.q[k].z = sp.q[k].w = 0.0f; }
+  }
+  return true;
+}
+
+// Slow path for the ragged end of the buffer: scalar reads (zeros past the end) straight into LDS, then
+// the mask words by ballot over LDS.  Called by the whole workgroup (contains a barrier).
+template <int MODE, int COUNT>
+__device__ __forceinline__ void span_fill_ragged(float* sx, unsigned long long* smask, int dst,
+                                                           const DetectArgs& a, long long src) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < COUNT; i += kThreads) sx[dst + i] = xg<MODE>(a.data, a.n, src + i);
+  __syncthreads();
+  for (int w = wave; w < COUNT / 64; w += kWaves) {
+    const unsigned long long m = __ballot(sx[dst + 64 * w + lane] >= a.thr);
+    if (lane == 0) smask[(dst >> 6) + w] = m;
   }
 }
 
@@ -323,7 +330,7 @@ __device__ __forceinline__ void span_commit(const Span<MODE, COUNT>& sp, float* 
 // tile; three barriers per tile.  Matched centres are appended to the workgroup's own slice of `cands`
 // in stream order; ordering across workgroups is by workgroup index (k_scan / k_gather).
 template <int MODE>
-__global__ void __launch_bounds__(kThreads) k_detect(DetectArgs a) {
+__global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs a) {
   __shared__ __attribute__((aligned(16))) float s_x[kWin];
   __shared__ unsigned long long s_mask[kWords];
   __shared__ unsigned short s_rise[kWaves][kQuarter / 2];
@@ -331,7 +338,7 @@ __global__ void __launch_bounds__(kThreads) k_detect(DetectArgs a) {
   __shared__ int s_nrec, s_pred;
   __shared__ unsigned s_flags;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = adsb_uniform(tid >> 6);
   const long long c0 = (long long)blockIdx.x * a.chunk;
   long long c1 = c0 + a.chunk;
   if (c1 > a.scan_hi) c1 = a.scan_hi;
@@ -354,19 +361,22 @@ __global__ void __launch_bounds__(kThreads) k_detect(DetectArgs a) {
 
   // prologue: head of the first tile straight into LDS (with its mask words), first body into registers
   Span<MODE, kTile> body;
+  bool body_ok = true;
   if (c0 < c1) {
     Span<MODE, kFwd> head;
-    span_issue<MODE, kFwd>(head, a, c0, wave, lane);
-    span_issue<MODE, kTile>(body, a, c0 + kFwd, wave, lane);
-    span_commit<MODE, kFwd>(head, s_x, s_mask, 0, a.thr, wave, lane);
+    const bool head_ok = span_issue<MODE, kFwd>(head, a, c0, wave, lane);
+    body_ok = span_issue<MODE, kTile>(body, a, c0 + kFwd, wave, lane);
+    if (head_ok) span_commit<MODE, kFwd>(head, s_x, s_mask, 0, a.thr, wave, lane);
+    else span_fill_ragged<MODE, kFwd>(s_x, s_mask, 0, a, c0);
   }
 
   for (long long t0 = c0; t0 < c1; t0 += kTile) {
     // -- A: window [t0, t0+kWin).  s_x[0..kFwd) and mask words 0..3 already hold the head; commit the body
     //       (floats + mask words 4..67), then start fetching the next body so it is in flight below
-    if (kAblate < 4) span_commit<MODE, kTile>(body, s_x, s_mask, kFwd, a.thr, wave, lane);
+    if (!body_ok) span_fill_ragged<MODE, kTile>(s_x, s_mask, kFwd, a, t0 + kFwd);
+    else if (kAblate < 4) span_commit<MODE, kTile>(body, s_x, s_mask, kFwd, a.thr, wave, lane);
     else { float acc = 0.0f; for (int k = 0; k < Span<MODE, kTile>::ITER; ++k) acc += body.q[k].x + body.q[k].w; if (acc == 123.456f) s_x[tid] = acc; }
-    if (t0 + kTile < c1) span_issue<MODE, kTile>(body, a, t0 + kTile + kFwd, wave, lane);
+    if (t0 + kTile < c1) body_ok = span_issue<MODE, kTile>(body, a, t0 + kTile + kFwd, wave, lane);
     __syncthreads();
 
     // -- B: every wavefront handles the rises of its own 16 mask words, no cross-wave sync inside
@@ -421,8 +431,9 @@ __global__ void __launch_bounds__(kThreads) k_detect(DetectArgs a) {
             const float hp = __fmul_rn(s_x[p], 0.5f);      // in0[pulse_idx]/2, exact
             unsigned chips = 0;
             if (p + 15 * half < kWin) {                    // all 16 taps inside the LDS window
-#pragma unroll
-              for (int k = 0; k < 16; ++k) chips |= (s_x[p + k * half] > hp ? 1u : 0u) << k;
+              const float* tp = s_x + p;
+#pragma unroll 4
+              for (int k = 0; k < 16; ++k) chips |= (tp[k * half] > hp ? 1u : 0u) << k;
             } else {                                       // rare: taps past the window come from global memory
 #pragma unroll 1
               for (int k = 0; k < 16; ++k) {

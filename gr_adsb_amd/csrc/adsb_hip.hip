@@ -19,6 +19,8 @@ __device__ __forceinline__ void adsb_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+__device__ __forceinline__ int adsb_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 #include "adsb_device.h"
 #include "adsb_plan.h"
 #include "../../include/adsb_hip.h"
@@ -45,6 +47,7 @@ struct adsb_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int n_cu = 256;
+  int bpc[2] = {4, 4};  // resident k_detect workgroups per CU (occupancy query), per input mode
   // framer state (framer.py:54,57)
   FramerState st;
   // device buffers
@@ -108,7 +111,9 @@ struct Misc {
 
 template <int MODE>
 void launch_detect(adsb_ctx* c, const DetectArgs& a, int grid) {
-  hipLaunchKernelGGL((k_detect<MODE>), dim3(grid), dim3(kThreads), 0, c->stream, a);
+  // ADSB_DEBUG_DYNLDS (bytes): tuning knob that pads the workgroup's LDS to lower occupancy on purpose
+  static const int dyn = getenv("ADSB_DEBUG_DYNLDS") ? atoi(getenv("ADSB_DEBUG_DYNLDS")) : 0;
+  hipLaunchKernelGGL((k_detect<MODE>), dim3(grid), dim3(kThreads), dyn, c->stream, a);
 }
 template <int MODE>
 void launch_burst(adsb_ctx* c, const DetectArgs& a, const unsigned long long* kept, const Summary* sum, unsigned orflags,
@@ -129,7 +134,9 @@ int run_pipeline(adsb_ctx* c, const Plan& pl, Summary* sum, int32_t* n_res) {
   const long long span = pl.scan_hi > 0 ? pl.scan_hi : 0;
   long long ntiles = (span + kTile - 1) / kTile;
   if (ntiles < 1) ntiles = 1;
-  const long long gmax = (long long)c->n_cu * 6;
+  // exactly one resident round of workgroups: a partial second round costs ~20 % (tail effect)
+  static const int bpc_env = getenv("ADSB_DEBUG_BPC") ? atoi(getenv("ADSB_DEBUG_BPC")) : 0;
+  const long long gmax = (long long)c->n_cu * (bpc_env > 0 ? bpc_env : c->bpc[pl.mode]);
   int grid = (int)(ntiles < gmax ? ntiles : gmax);
   const long long tiles_per = (ntiles + grid - 1) / grid;
   grid = (int)((ntiles + tiles_per - 1) / tiles_per);
@@ -169,6 +176,7 @@ int run_pipeline(adsb_ctx* c, const Plan& pl, Summary* sum, int32_t* n_res) {
     const bool timing = (c->flags & ADSB_FLAG_TIMING) != 0;
     if (timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (pl.mode == 0) launch_detect<0>(c, a, grid); else launch_detect<1>(c, a, grid);
+    c->stats.detect_grid = (uint64_t)grid; c->stats.blocks_per_cu = (uint64_t)c->bpc[pl.mode];
     if (timing) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
 
     bool did_long = false;
@@ -302,6 +310,11 @@ int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx
   if (hipSetDevice(device) != hipSuccess) { delete c; return -ENODEV; }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+  {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_detect<0>, kThreads, 0) == hipSuccess && nb > 0) c->bpc[0] = nb;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_detect<1>, kThreads, 0) == hipSuccess && nb > 0) c->bpc[1] = nb;
+  }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return -EIO; }
   c->own_stream = true;
   if (hipHostMalloc((void**)&c->h_sum, sizeof(Summary), hipHostMallocDefault) != hipSuccess) { adsb_destroy(c); return -ENOMEM; }

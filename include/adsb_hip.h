@@ -58,6 +58,8 @@ typedef struct adsb_stats {
   uint64_t calls;
   uint64_t retries;          /* record-capacity regrowths */
   uint64_t longrun_calls;    /* calls that needed the long-pulse kernel */
+  uint64_t detect_grid;      /* workgroups of the last k_detect launch */
+  uint64_t blocks_per_cu;    /* resident k_detect workgroups per CU (occupancy query) */
 } adsb_stats;
 
 int adsb_abi_version(void);

@@ -193,6 +193,8 @@ inline void adsb_wave_sync() {
   hipsim::wave_sync(b->waves[b->cur >> 6]);
 }
 
+inline int adsb_uniform(int v) { return v; }
+
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline unsigned long long __brevll(unsigned long long v) {
   unsigned long long r = 0;

@@ -29,7 +29,7 @@ for _ in range(%(steps)d): nb = fe.process_iq_tensor(iq, 0, fetch=False)
 torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/%(steps)d
 st = fe.stats()
 k = st["detect_ms"]/st["detect_launches"]
-print(json.dumps(dict(kernel_ms=round(k,4), step_ms=round(dt*1e3,4), gbs=round(8*n/k/1e6,1), bursts=int(nb))))
+print(json.dumps(dict(kernel_ms=round(k,4), step_ms=round(dt*1e3,4), gbs=round(8*n/k/1e6,1), bursts=int(nb), grid=st["detect_grid"], bpc=st["blocks_per_cu"])))
 '''
 
 

@@ -101,11 +101,17 @@ def main():
     torch.cuda.synchronize()
 
     tails = None
+    pending = []          # tickets of submitted, not yet collected passes (N=1: two-deep pipeline)
 
     def step():
         nonlocal tails
         if n_gpus == 1:
-            return fe.process_iq_tensor(iq, 0, fetch=False)
+            # submit pass i+1 before collecting pass i: the PCIe copy and host work of one pass overlap the
+            # kernels of the next; every pass is collected inside the timed region (drain() below)
+            pending.append(fe.submit_iq_tensor(iq, 0))
+            if len(pending) == 2:
+                return fe.wait(pending.pop(0), fetch=False)
+            return 0
         cands = fe.shard_tensor(iq, plan["lo"], plan["own_lo"], plan["own_hi"], stream_len)
         kept = _native.stitch(cands, sps)                      # local gate, fresh state
         # exchange the 8-byte tail state; fix the head of this shard against the previous shard's tail
@@ -138,6 +144,12 @@ def main():
         rest = kept[kept["offset"] >= off[head]] if head < len(off) else kept[:0]
         return np.concatenate([pre, rest])
 
+    def drain():
+        n = 0
+        while pending:
+            n = fe.wait(pending.pop(0), fetch=False)
+        return n
+
     def sync_all():
         if n_gpus > 1:
             dist.barrier()
@@ -145,12 +157,15 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     fe.ctx.reset_stats()
     sync_all()
     t0 = time.perf_counter()
     n_bursts = 0
     for _ in range(args.steps):
         n_bursts = step()
+    if n_gpus == 1:
+        n_bursts = drain()
     sync_all()
     elapsed = time.perf_counter() - t0
     if n_gpus > 1:
@@ -185,6 +200,8 @@ def main():
                             % (fs / 1e6, args.bursts, args.threshold, args.log2n),
                 "fs": fs, "samples_per_gpu_per_step": n_own, "bursts_per_step_rank0": int(n_bursts),
                 "sharding": "none" if n_gpus == 1 else "%d overlapped time shards, host stitch" % n_gpus,
+                "pipeline": "2 passes in flight (submit/wait)" if n_gpus == 1 else "blocking",
+                "detect_grid": int(st["detect_grid"]), "retries": int(st["retries"]), "longrun_calls": int(st["longrun_calls"]),
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_detect<complex64>",

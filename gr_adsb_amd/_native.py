@@ -21,6 +21,7 @@ BURST_KEPT = 2
 EXPORTS = [
     "adsb_abi_version", "adsb_create", "adsb_destroy", "adsb_set_threshold", "adsb_set_stream", "adsb_reset",
     "adsb_process_iq", "adsb_process_mag2", "adsb_process_iq_device", "adsb_process_mag2_device", "adsb_last_result",
+    "adsb_submit_iq_device", "adsb_submit_mag2_device", "adsb_wait",
     "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_stitch", "adsb_snr_db", "adsb_get_stats",
     "adsb_reset_stats", "adsb_last_error",
 ]
@@ -72,6 +73,9 @@ def load():
     for name in ("adsb_process_iq", "adsb_process_mag2", "adsb_process_iq_device", "adsb_process_mag2_device"):
         getattr(lib, name).argtypes = [vp, vp, i64, i64, vp, i32, c.POINTER(i32)]
     lib.adsb_last_result.argtypes = [vp, c.POINTER(vp), c.POINTER(i32)]
+    lib.adsb_submit_iq_device.argtypes = [vp, vp, i64, i64, c.POINTER(i32)]
+    lib.adsb_submit_mag2_device.argtypes = [vp, vp, i64, i64, c.POINTER(i32)]
+    lib.adsb_wait.argtypes = [vp, i32, vp, i32, c.POINTER(i32)]
     lib.adsb_framer_work.argtypes = [vp, vp, i64, i64, i64, vp, i32, c.POINTER(i32)]
     lib.adsb_demod_work.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp, vp]
     lib.adsb_shard_device.argtypes = [vp, c.c_int, vp, i64, i64, i64, i64, i64, vp, i32, c.POINTER(i32)]
@@ -155,6 +159,21 @@ class Context:
         n_out = ctypes.c_int32(0)
         self._chk(self.lib.adsb_process_mag2_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(n), int(abs_offset), None, 0,
                                                     ctypes.byref(n_out)))
+        return self.last_result() if fetch else n_out.value
+
+    def submit_iq_device(self, dev_ptr, n, abs_offset=0):
+        t = ctypes.c_int32(-1)
+        self._chk(self.lib.adsb_submit_iq_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(n), int(abs_offset), ctypes.byref(t)))
+        return t.value
+
+    def submit_mag2_device(self, dev_ptr, n, abs_offset=0):
+        t = ctypes.c_int32(-1)
+        self._chk(self.lib.adsb_submit_mag2_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(n), int(abs_offset), ctypes.byref(t)))
+        return t.value
+
+    def wait(self, ticket, fetch=True):
+        n_out = ctypes.c_int32(0)
+        self._chk(self.lib.adsb_wait(self._h, int(ticket), None, 0, ctypes.byref(n_out)))
         return self.last_result() if fetch else n_out.value
 
     def framer_work(self, in0, N, nitems_written):

@@ -538,11 +538,14 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
 
 // ---- k_longrun: pulses whose run leaves the LDS window (or starts in the zero history) -------------
 // One workgroup per entry scans forward cooperatively for the fall, then wave 0 finishes the pulse
-// with global-memory taps and overwrites the placeholder.  Rare (CW / overload): correctness path.
+// with global-memory taps and overwrites the placeholder.  Rare (CW / overload, or dense overlapping
+// bursts): it is launched after every k_detect and returns at once when the list is empty.
 template <int MODE>
-__global__ void __launch_bounds__(kThreads) k_longrun(DetectArgs a, int n_entries) {
+__global__ void __launch_bounds__(kThreads) k_longrun(DetectArgs a) {
   __shared__ unsigned long long s_found;   // fall index relative to rise+1
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int n_entries = *a.long_count;                 // written by k_detect, usually 0: then this kernel is a no-op
+  if (n_entries > a.long_cap) n_entries = a.long_cap;
   for (int e = blockIdx.x; e < n_entries; e += gridDim.x) {
     const LongRise le = a.longlist[e];
     const long long limit = a.fall_hi;

@@ -36,6 +36,31 @@ struct DevBuf {
   size_t cap = 0;
 };
 
+// d_misc layout: [0] int long_count, [8] u64 long_lastp, [64] Summary
+struct Misc {
+  int long_count;
+  int pad;
+  unsigned long long long_lastp;
+  char fill[48];
+  Summary sum;
+};
+
+// Everything one in-flight call needs on the device and in pinned host memory.  Two slots let call i+1
+// run on the GPU while the records of call i travel over PCIe (adsb_submit_* / adsb_wait).
+struct Slot {
+  DevBuf d_cands, d_sorted, d_kept, d_out, d_seg, d_blk_count, d_blk_lastp, d_blk_flags, d_blk_off, d_long, d_misc;
+  Summary* h_sum = nullptr;      // pinned
+  void* h_out = nullptr;         // pinned burst records of the finished call
+  size_t h_out_cap = 0;
+  hipEvent_t done = nullptr, ev0 = nullptr, ev1 = nullptr;
+  bool busy = false;
+  Plan plan{};
+  DetectArgs args{};
+  int grid = 0, rec_cap = 0;
+  long long tot = 0, ntiles = 0, chunk = 0, span = 0;
+  int32_t nres = 0;
+};
+
 }  // namespace
 
 struct adsb_ctx {
@@ -44,24 +69,19 @@ struct adsb_ctx {
   int sps = 0;
   float thr = 0;
   uint32_t flags = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;       // compute
+  hipStream_t copy_stream = nullptr;  // device -> pinned host result copies
   bool own_stream = false;
   int n_cu = 256;
   int bpc[2] = {4, 4};  // resident k_detect workgroups per CU (occupancy query), per input mode
-  // framer state (framer.py:54,57)
-  FramerState st;
-  // device buffers
-  DevBuf d_in, d_cands, d_kept, d_blk_count, d_blk_lastp, d_blk_flags, d_blk_off, d_long, d_misc, d_sorted, d_seg, d_out,
-      d_tags, d_bits, d_ok, d_ratio;
+  FramerState st;       // framer.py:54,57
+  Slot slot[2];
+  int next_slot = 0;
+  int last_slot = 0;
+  DevBuf d_in, d_tags, d_bits, d_ok, d_ratio;
   int rec_cap_shift = 0;  // rec_cap multiplier (grows on overflow)
-  // pinned host
-  Summary* h_sum = nullptr;
-  void* h_out = nullptr;
-  size_t h_out_cap = 0;
   void* h_stage = nullptr;
   size_t h_stage_cap = 0;
-  int32_t last_n = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   adsb_stats stats{};
   char err[256] = {0};
 };
@@ -100,15 +120,6 @@ int ensure_pinned(adsb_ctx* c, void*& p, size_t& cap, size_t bytes) {
   return 0;
 }
 
-// d_misc layout: [0] int long_count, [8] u64 long_lastp, [64] Summary
-struct Misc {
-  int long_count;
-  int pad;
-  unsigned long long long_lastp;
-  char fill[48];
-  Summary sum;
-};
-
 template <int MODE>
 void launch_detect(adsb_ctx* c, const DetectArgs& a, int grid) {
   // ADSB_DEBUG_DYNLDS (bytes): tuning knob that pads the workgroup's LDS to lower occupancy on purpose
@@ -121,18 +132,48 @@ void launch_burst(adsb_ctx* c, const DetectArgs& a, const unsigned long long* ke
   hipLaunchKernelGGL((k_burst<MODE>), dim3(c->n_cu * 8), dim3(kThreads), 0, c->stream, a, kept, sum, orflags, out, cap);
 }
 template <int MODE>
-void launch_longrun(adsb_ctx* c, const DetectArgs& a, int n) {
-  int g = n < 256 ? n : 256;
-  hipLaunchKernelGGL((k_longrun<MODE>), dim3(g), dim3(kThreads), 0, c->stream, a, n);
+void launch_longrun(adsb_ctx* c, const DetectArgs& a) {
+  hipLaunchKernelGGL((k_longrun<MODE>), dim3(64), dim3(kThreads), 0, c->stream, a);
 }
 
-// Runs the whole device pipeline for one plan.  On return the kept (or all matched) records are in
-// c->h_out (pinned), count in *n_res, and *sum holds the device summary.
-int run_pipeline(adsb_ctx* c, const Plan& pl, Summary* sum, int32_t* n_res) {
+// Everything after k_detect (and after k_longrun on the rare second pass): order, gate, compact, records.
+int enqueue_tail(adsb_ctx* c, Slot& s) {
+  const DetectArgs& a = s.args;
+  const Plan& pl = s.plan;
+  Misc* misc = (Misc*)s.d_misc.p;
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(kThreads), 0, c->stream, (const int*)a.blk_count,
+                     (const long long*)a.blk_lastp, (const unsigned*)a.blk_flags, s.grid, s.rec_cap,
+                     (const int*)a.long_count, (const unsigned long long*)a.long_lastp, (int*)s.d_blk_off.p, &misc->sum);
+  const int gg = s.grid < 1024 ? s.grid : 1024;
+  unsigned long long* sorted = (unsigned long long*)s.d_sorted.p;
+  unsigned long long* kept = (unsigned long long*)s.d_kept.p;
+  hipLaunchKernelGGL(k_gather, dim3(gg), dim3(kThreads), 0, c->stream, (const unsigned long long*)a.cands,
+                     (const int*)a.blk_count, (const int*)s.d_blk_off.p, s.grid, s.rec_cap, sorted);
+  const int ag = 512;
+  unsigned fmask = kNoMatch | kPending, fwant = 0u, orflags = 0u;
+  if (pl.gate) {
+    hipLaunchKernelGGL(k_resolve, dim3(ag), dim3(kThreads), 0, c->stream, sorted, (const Summary*)&misc->sum,
+                       (long long)63 * c->sps, pl.prev_eob_stream - pl.origin);
+    fmask = kKept; fwant = kKept; orflags = kKept;
+  }
+  hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, c->stream, (const unsigned long long*)sorted,
+                     (const Summary*)&misc->sum, fmask, fwant, (int*)s.d_seg.p);
+  hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kThreads), 0, c->stream, (int*)s.d_seg.p, &misc->sum);
+  hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, c->stream, (const unsigned long long*)sorted, &misc->sum,
+                     (const int*)s.d_seg.p, fmask, fwant, kept, (int)s.tot);
+  if (pl.mode == 0) launch_burst<0>(c, a, kept, &misc->sum, orflags, (Rec*)s.d_out.p, (int)s.tot);
+  else launch_burst<1>(c, a, kept, &misc->sum, orflags, (Rec*)s.d_out.p, (int)s.tot);
+  HIPCHK(c, hipMemcpyAsync(s.h_sum, &misc->sum, sizeof(Summary), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(s.done, c->stream));
+  return 0;
+}
+
+// Queue the whole device pipeline of one plan on the compute stream; nothing here waits for the GPU.
+int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   HIPCHK(c, hipSetDevice(c->device));
-  c->stats.calls++;
-  const long long span = pl.scan_hi > 0 ? pl.scan_hi : 0;
-  long long ntiles = (span + kTile - 1) / kTile;
+  s.plan = pl;
+  s.span = pl.scan_hi > 0 ? pl.scan_hi : 0;
+  long long ntiles = (s.span + kTile - 1) / kTile;
   if (ntiles < 1) ntiles = 1;
   // exactly one resident round of workgroups: a partial second round costs ~20 % (tail effect)
   static const int bpc_env = getenv("ADSB_DEBUG_BPC") ? atoi(getenv("ADSB_DEBUG_BPC")) : 0;
@@ -141,118 +182,103 @@ int run_pipeline(adsb_ctx* c, const Plan& pl, Summary* sum, int32_t* n_res) {
   const long long tiles_per = (ntiles + grid - 1) / grid;
   grid = (int)((ntiles + tiles_per - 1) / tiles_per);
   const long long chunk = tiles_per * kTile;
+  long long rc = (chunk / 256 + 64) << c->rec_cap_shift;
+  if (rc > chunk / 2 + 8) rc = chunk / 2 + 8;   // there can never be more rises than that
+  s.grid = grid; s.rec_cap = (int)rc; s.tot = (long long)grid * rc; s.ntiles = ntiles; s.chunk = chunk;
+  const long long long_cap = ntiles + 1;        // at most one long pulse per tile, plus the virtual rise
+  int r;
+  if ((r = ensure(c, s.d_cands, (size_t)s.tot * 8))) return r;
+  if ((r = ensure(c, s.d_sorted, (size_t)s.tot * 8))) return r;
+  if ((r = ensure(c, s.d_kept, (size_t)s.tot * 8))) return r;
+  if ((r = ensure(c, s.d_out, (size_t)s.tot * sizeof(Rec)))) return r;
+  if ((r = ensure(c, s.d_seg, (size_t)(s.tot / kThreads + 2) * sizeof(int)))) return r;
+  if ((r = ensure(c, s.d_blk_count, (size_t)grid * sizeof(int)))) return r;
+  if ((r = ensure(c, s.d_blk_lastp, (size_t)grid * sizeof(long long)))) return r;
+  if ((r = ensure(c, s.d_blk_flags, (size_t)grid * sizeof(unsigned)))) return r;
+  if ((r = ensure(c, s.d_blk_off, (size_t)grid * sizeof(int)))) return r;
+  if ((r = ensure(c, s.d_long, (size_t)long_cap * sizeof(LongRise)))) return r;
+  if ((r = ensure(c, s.d_misc, sizeof(Misc)))) return r;
+  Misc* misc = (Misc*)s.d_misc.p;
 
-  for (int attempt = 0; attempt < 12; ++attempt) {
-    long long rc = (chunk / 256 + 64) << c->rec_cap_shift;
-    if (rc > chunk / 2 + 8) rc = chunk / 2 + 8;   // can never have more rises than that
-    const int rec_cap = (int)rc;
-    const long long tot = (long long)grid * rec_cap;
-    const int long_cap = grid + 1;  // at most one long pulse per tile that ends a chunk... bounded by tiles
-    const long long long_cap_ll = ntiles + 1;
-    int rcx;
-    if ((rcx = ensure(c, c->d_cands, (size_t)tot * 8))) return rcx;
-    if ((rcx = ensure(c, c->d_sorted, (size_t)tot * 8))) return rcx;
-    if ((rcx = ensure(c, c->d_kept, (size_t)tot * 8))) return rcx;
-    if ((rcx = ensure(c, c->d_out, (size_t)tot * sizeof(Rec)))) return rcx;
-    if ((rcx = ensure(c, c->d_seg, (size_t)(tot / kThreads + 2) * sizeof(int)))) return rcx;
-    if ((rcx = ensure(c, c->d_blk_count, (size_t)grid * sizeof(int)))) return rcx;
-    if ((rcx = ensure(c, c->d_blk_lastp, (size_t)grid * sizeof(long long)))) return rcx;
-    if ((rcx = ensure(c, c->d_blk_flags, (size_t)grid * sizeof(unsigned)))) return rcx;
-    if ((rcx = ensure(c, c->d_blk_off, (size_t)grid * sizeof(int)))) return rcx;
-    if ((rcx = ensure(c, c->d_long, (size_t)long_cap_ll * sizeof(LongRise)))) return rcx;
-    if ((rcx = ensure(c, c->d_misc, sizeof(Misc)))) return rcx;
-    (void)long_cap;
-    Misc* misc = (Misc*)c->d_misc.p;
+  DetectArgs& a = s.args;
+  a.data = pl.d_data; a.n = pl.n; a.in0_base = pl.in0_base; a.scan_lo = pl.scan_lo; a.scan_hi = pl.scan_hi;
+  a.fall_hi = pl.fall_hi; a.dem_hi = pl.dem_hi; a.origin = pl.origin; a.chunk = chunk; a.thr = c->thr;
+  a.prev_in0 = pl.prev_in0; a.sps = c->sps; a.end_is_call_end = pl.end_is_call_end; a.rec_cap = s.rec_cap;
+  a.long_cap = (int)long_cap; a.cands = (unsigned long long*)s.d_cands.p; a.blk_count = (int*)s.d_blk_count.p;
+  a.blk_lastp = (long long*)s.d_blk_lastp.p; a.blk_flags = (unsigned*)s.d_blk_flags.p;
+  a.longlist = (LongRise*)s.d_long.p; a.long_count = &misc->long_count; a.long_lastp = &misc->long_lastp;
 
-    DetectArgs a;
-    a.data = pl.d_data; a.n = pl.n; a.in0_base = pl.in0_base; a.scan_lo = pl.scan_lo; a.scan_hi = pl.scan_hi;
-    a.fall_hi = pl.fall_hi; a.dem_hi = pl.dem_hi; a.origin = pl.origin; a.chunk = chunk; a.thr = c->thr;
-    a.prev_in0 = pl.prev_in0; a.sps = c->sps; a.end_is_call_end = pl.end_is_call_end; a.rec_cap = rec_cap;
-    a.long_cap = (int)long_cap_ll; a.cands = (unsigned long long*)c->d_cands.p; a.blk_count = (int*)c->d_blk_count.p;
-    a.blk_lastp = (long long*)c->d_blk_lastp.p; a.blk_flags = (unsigned*)c->d_blk_flags.p;
-    a.longlist = (LongRise*)c->d_long.p; a.long_count = &misc->long_count; a.long_lastp = &misc->long_lastp;
+  HIPCHK(c, hipMemsetAsync(misc, 0, 16, c->stream));
+  const bool timing = (c->flags & ADSB_FLAG_TIMING) != 0;
+  if (timing) HIPCHK(c, hipEventRecord(s.ev0, c->stream));
+  if (pl.mode == 0) launch_detect<0>(c, a, grid); else launch_detect<1>(c, a, grid);
+  if (timing) HIPCHK(c, hipEventRecord(s.ev1, c->stream));
+  if (pl.mode == 0) launch_longrun<0>(c, a); else launch_longrun<1>(c, a);   // no-op unless k_detect listed long pulses
+  c->stats.detect_grid = (uint64_t)grid; c->stats.blocks_per_cu = (uint64_t)c->bpc[pl.mode];
+  c->stats.calls++;
+  s.busy = true;
+  return enqueue_tail(c, s);
+}
 
-    HIPCHK(c, hipMemsetAsync(misc, 0, 16, c->stream));
-    const bool timing = (c->flags & ADSB_FLAG_TIMING) != 0;
-    if (timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (pl.mode == 0) launch_detect<0>(c, a, grid); else launch_detect<1>(c, a, grid);
-    c->stats.detect_grid = (uint64_t)grid; c->stats.blocks_per_cu = (uint64_t)c->bpc[pl.mode];
-    if (timing) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-
-    bool did_long = false;
-    for (;;) {
-      hipLaunchKernelGGL(k_scan, dim3(1), dim3(kThreads), 0, c->stream, (const int*)a.blk_count,
-                         (const long long*)a.blk_lastp, (const unsigned*)a.blk_flags, grid, rec_cap,
-                         (const int*)a.long_count, (const unsigned long long*)a.long_lastp, (int*)c->d_blk_off.p,
-                         &misc->sum);
-      int gg = grid < 1024 ? grid : 1024;
-      unsigned long long* sorted = (unsigned long long*)c->d_sorted.p;
-      unsigned long long* kept = (unsigned long long*)c->d_kept.p;
-      hipLaunchKernelGGL(k_gather, dim3(gg), dim3(kThreads), 0, c->stream, (const unsigned long long*)a.cands,
-                         (const int*)a.blk_count, (const int*)c->d_blk_off.p, grid, rec_cap, sorted);
-      const int ag = 512;
-      unsigned fmask = kNoMatch | kPending, fwant = 0u, orflags = 0u;
-      if (pl.gate) {
-        hipLaunchKernelGGL(k_resolve, dim3(ag), dim3(kThreads), 0, c->stream, sorted, (const Summary*)&misc->sum,
-                           (long long)63 * c->sps, pl.prev_eob_stream - pl.origin);
-        fmask = kKept; fwant = kKept; orflags = kKept;
-      }
-      hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, c->stream, (const unsigned long long*)sorted,
-                         (const Summary*)&misc->sum, fmask, fwant, (int*)c->d_seg.p);
-      hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kThreads), 0, c->stream, (int*)c->d_seg.p, &misc->sum);
-      hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, c->stream, (const unsigned long long*)sorted,
-                         &misc->sum, (const int*)c->d_seg.p, fmask, fwant, kept, (int)tot);
-      if (pl.mode == 0) launch_burst<0>(c, a, kept, &misc->sum, orflags, (Rec*)c->d_out.p, (int)tot);
-      else launch_burst<1>(c, a, kept, &misc->sum, orflags, (Rec*)c->d_out.p, (int)tot);
-      HIPCHK(c, hipMemcpyAsync(c->h_sum, &misc->sum, sizeof(Summary), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      HIPCHK(c, hipGetLastError());
-      if (c->h_sum->long_count > 0 && !did_long && !c->h_sum->overflow) {
-        // rare: pulses longer than the LDS window (or starting in the zero history)
-        did_long = true;
-        c->stats.longrun_calls++;
-        int nl = c->h_sum->long_count;
-        if (nl > (int)long_cap_ll) return fail(c, -EIO, "long-rise list overflow");
-        if (pl.mode == 0) launch_longrun<0>(c, a, nl); else launch_longrun<1>(c, a, nl);
-        continue;
-      }
-      break;
-    }
+// Wait for a queued call; handle the two rare outcomes that need a second pass (pulses longer than the
+// LDS window; per-workgroup list overflow); bring the records to pinned host memory.
+int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
+  HIPCHK(c, hipSetDevice(c->device));
+  const bool timing = (c->flags & ADSB_FLAG_TIMING) != 0;
+  for (int attempt = 0; attempt < 16; ++attempt) {
+    HIPCHK(c, hipEventSynchronize(s.done));
+    HIPCHK(c, hipGetLastError());
     if (timing) {
       float ms = 0;
-      HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+      HIPCHK(c, hipEventElapsedTime(&ms, s.ev0, s.ev1));
       c->stats.detect_launches++;
       c->stats.detect_ms += ms;
-      c->stats.detect_samples += (uint64_t)(span > 0 ? span : 0);
-      c->stats.detect_bytes += (uint64_t)(span > 0 ? span : 0) * (pl.mode == 0 ? 8u : 4u);
+      c->stats.detect_samples += (uint64_t)s.span;
+      c->stats.detect_bytes += (uint64_t)s.span * (s.plan.mode == 0 ? 8u : 4u);
     }
-    if (c->h_sum->overflow) {
+    if (s.h_sum->overflow) {
+      if ((long long)s.rec_cap >= s.chunk / 2 + 8) { s.busy = false; return fail(c, -EIO, "centre list overflow at maximum size"); }
       c->rec_cap_shift++;
       c->stats.retries++;
-      if (rc >= chunk / 2 + 8) return fail(c, -EIO, "record capacity overflow at maximum size");
+      int r = enqueue(c, s, s.plan);
+      if (r) { s.busy = false; return r; }
+      c->stats.calls--;
       continue;
     }
-    *sum = *c->h_sum;
+    if (s.h_sum->long_count > 0) c->stats.longrun_calls++;
+    if (s.h_sum->long_count > s.args.long_cap) { s.busy = false; return fail(c, -EIO, "long-rise list overflow"); }
+    *sum = *s.h_sum;
     const int nres = sum->n_kept;
-    int rcx2;
-    if ((rcx2 = ensure_pinned(c, c->h_out, c->h_out_cap, (size_t)(nres > 0 ? nres : 1) * sizeof(Rec)))) return rcx2;
+    int r = ensure_pinned(c, s.h_out, s.h_out_cap, (size_t)(nres > 0 ? nres : 1) * sizeof(Rec));
+    if (r) { s.busy = false; return r; }
     if (nres > 0) {
-      const void* src = c->d_out.p;
-      HIPCHK(c, hipMemcpyAsync(c->h_out, src, (size_t)nres * sizeof(Rec), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipMemcpyAsync(s.h_out, s.d_out.p, (size_t)nres * sizeof(Rec), hipMemcpyDeviceToHost, c->copy_stream));
+      HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     }
+    s.nres = nres;
     *n_res = nres;
-    c->last_n = nres;
+    s.busy = false;
     return 0;
   }
-  return fail(c, -EIO, "record capacity did not converge");
+  s.busy = false;
+  return fail(c, -EIO, "centre list capacity did not converge");
+}
+
+// Synchronous form used by every blocking entry point.
+int run_pipeline(adsb_ctx* c, const Plan& pl, Summary* sum, int32_t* n_res) {
+  if (c->slot[0].busy || c->slot[1].busy) return fail(c, -EBUSY, "a submitted call is still pending (adsb_wait first)");
+  Slot& s = c->slot[0];
+  c->last_slot = 0;
+  int r = enqueue(c, s, pl);
+  if (r) { s.busy = false; return r; }
+  return finish(c, s, sum, n_res);
 }
 
 int deliver(adsb_ctx* c, int32_t nres, adsb_burst* out, int32_t cap, int32_t* n_out) {
   if (n_out) *n_out = nres;
   if (out) {
     if (nres > cap) return fail(c, -ENOSPC, "output array too small");
-    if (nres > 0) memcpy(out, c->h_out, (size_t)nres * sizeof(adsb_burst));
+    if (nres > 0) memcpy(out, c->slot[c->last_slot].h_out, (size_t)nres * sizeof(adsb_burst));
   }
   return 0;
 }
@@ -264,7 +290,7 @@ int canonical(adsb_ctx* c, int mode, const void* d_data, int64_t n, int64_t abs_
   Plan pl = plan_canonical(mode, d_data, n, abs_offset, c->sps);
   Summary s;
   int32_t nres = 0;
-  if (n == 0) { c->last_n = 0; if (n_out) *n_out = 0; return 0; }
+  if (n == 0) { c->slot[c->last_slot].nres = 0; if (n_out) *n_out = 0; return 0; }
   int rc = run_pipeline(c, pl, &s, &nres);
   if (rc) return rc;
   return deliver(c, nres, out, cap, n_out);
@@ -317,8 +343,12 @@ int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx
   }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return -EIO; }
   c->own_stream = true;
-  if (hipHostMalloc((void**)&c->h_sum, sizeof(Summary), hipHostMallocDefault) != hipSuccess) { adsb_destroy(c); return -ENOMEM; }
-  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { adsb_destroy(c); return -EIO; }
+  if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { adsb_destroy(c); return -EIO; }
+  for (Slot& sl : c->slot) {
+    if (hipHostMalloc((void**)&sl.h_sum, sizeof(Summary), hipHostMallocDefault) != hipSuccess) { adsb_destroy(c); return -ENOMEM; }
+    if (hipEventCreate(&sl.ev0) != hipSuccess || hipEventCreate(&sl.ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) { adsb_destroy(c); return -EIO; }
+  }
   *out = c;
   return 0;
 }
@@ -327,14 +357,21 @@ void adsb_destroy(adsb_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  DevBuf* bufs[] = {&c->d_in, &c->d_cands, &c->d_kept, &c->d_blk_count, &c->d_blk_lastp, &c->d_blk_flags, &c->d_blk_off, &c->d_long,
-                    &c->d_misc, &c->d_sorted, &c->d_seg, &c->d_out, &c->d_tags, &c->d_bits, &c->d_ok, &c->d_ratio};
+  if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+  DevBuf* bufs[] = {&c->d_in, &c->d_tags, &c->d_bits, &c->d_ok, &c->d_ratio};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
-  if (c->h_sum) (void)hipHostFree(c->h_sum);
-  if (c->h_out) (void)hipHostFree(c->h_out);
+  for (Slot& sl : c->slot) {
+    DevBuf* sb[] = {&sl.d_cands, &sl.d_sorted, &sl.d_kept, &sl.d_out, &sl.d_seg, &sl.d_blk_count, &sl.d_blk_lastp,
+                    &sl.d_blk_flags, &sl.d_blk_off, &sl.d_long, &sl.d_misc};
+    for (DevBuf* b : sb) if (b->p) (void)hipFree(b->p);
+    if (sl.h_sum) (void)hipHostFree(sl.h_sum);
+    if (sl.h_out) (void)hipHostFree(sl.h_out);
+    if (sl.ev0) (void)hipEventDestroy(sl.ev0);
+    if (sl.ev1) (void)hipEventDestroy(sl.ev1);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+  }
   if (c->h_stage) (void)hipHostFree(c->h_stage);
-  if (c->ev0) (void)hipEventDestroy(c->ev0);
-  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -347,6 +384,7 @@ int adsb_set_threshold(adsb_ctx* c, float threshold) {
 
 int adsb_set_stream(adsb_ctx* c, void* hip_stream) {
   if (!c) return -EINVAL;
+  if (c->slot[0].busy || c->slot[1].busy) return fail(c, -EBUSY, "calls pending");
   if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
   c->stream = (hipStream_t)hip_stream;
   c->own_stream = false;
@@ -372,7 +410,7 @@ int adsb_process_mag2_device(adsb_ctx* c, const void* d_mag2, int64_t n, int64_t
 int adsb_process_iq(adsb_ctx* c, const float* iq_host, int64_t n, int64_t abs_offset, adsb_burst* out,
                     int32_t cap, int32_t* n_out) {
   if (!c || n < 0 || (n > 0 && !iq_host)) return -EINVAL;
-  if (n == 0) { if (n_out) *n_out = 0; c->last_n = 0; return 0; }
+  if (n == 0) { if (n_out) *n_out = 0; c->slot[c->last_slot].nres = 0; return 0; }
   HIPCHK(c, hipSetDevice(c->device));
   void* d = nullptr;
   int rc = upload(c, iq_host, (size_t)n * 8, &d);
@@ -383,7 +421,7 @@ int adsb_process_iq(adsb_ctx* c, const float* iq_host, int64_t n, int64_t abs_of
 int adsb_process_mag2(adsb_ctx* c, const float* mag2_host, int64_t n, int64_t abs_offset, adsb_burst* out,
                       int32_t cap, int32_t* n_out) {
   if (!c || n < 0 || (n > 0 && !mag2_host)) return -EINVAL;
-  if (n == 0) { if (n_out) *n_out = 0; c->last_n = 0; return 0; }
+  if (n == 0) { if (n_out) *n_out = 0; c->slot[c->last_slot].nres = 0; return 0; }
   HIPCHK(c, hipSetDevice(c->device));
   void* d = nullptr;
   int rc = upload(c, mag2_host, (size_t)n * 4, &d);
@@ -391,10 +429,43 @@ int adsb_process_mag2(adsb_ctx* c, const float* mag2_host, int64_t n, int64_t ab
   return canonical(c, 1, d, n, abs_offset, out, cap, n_out);
 }
 
+static int submit_canonical(adsb_ctx* c, int mode, const void* d_data, int64_t n, int64_t abs_offset, int32_t* ticket) {
+  if (!c || n < 1 || !ticket) return -EINVAL;
+  if (((uintptr_t)d_data & 15u) != 0) return fail(c, -EINVAL, "device pointer must be 16-byte aligned");
+  Slot& s = c->slot[c->next_slot];
+  if (s.busy) return fail(c, -EBUSY, "both pipeline slots are in flight (adsb_wait first)");
+  Plan pl = plan_canonical(mode, d_data, n, abs_offset, c->sps);
+  int r = enqueue(c, s, pl);
+  if (r) { s.busy = false; return r; }
+  *ticket = c->next_slot;
+  c->next_slot ^= 1;
+  return 0;
+}
+
+int adsb_submit_iq_device(adsb_ctx* c, const void* d_iq, int64_t n, int64_t abs_offset, int32_t* ticket) {
+  return submit_canonical(c, 0, d_iq, n, abs_offset, ticket);
+}
+
+int adsb_submit_mag2_device(adsb_ctx* c, const void* d_mag2, int64_t n, int64_t abs_offset, int32_t* ticket) {
+  return submit_canonical(c, 1, d_mag2, n, abs_offset, ticket);
+}
+
+int adsb_wait(adsb_ctx* c, int32_t ticket, adsb_burst* out, int32_t cap, int32_t* n_out) {
+  if (!c || ticket < 0 || ticket > 1) return -EINVAL;
+  Slot& s = c->slot[ticket];
+  if (!s.busy) return fail(c, -EINVAL, "no call pending on this ticket");
+  Summary sum;
+  int32_t nres = 0;
+  int r = finish(c, s, &sum, &nres);
+  if (r) return r;
+  c->last_slot = ticket;
+  return deliver(c, nres, out, cap, n_out);
+}
+
 int adsb_last_result(adsb_ctx* c, const adsb_burst** bursts, int32_t* n) {
   if (!c) return -EINVAL;
-  if (bursts) *bursts = (const adsb_burst*)c->h_out;
-  if (n) *n = c->last_n;
+  if (bursts) *bursts = (const adsb_burst*)c->slot[c->last_slot].h_out;
+  if (n) *n = c->slot[c->last_slot].nres;
   return 0;
 }
 
@@ -469,7 +540,7 @@ int adsb_shard_device(adsb_ctx* c, int fmt, const void* d_data, int64_t n, int64
   if (rc) return rc;
   if (s.flags & 4u) return fail(c, -EOVERFLOW, "pulse runs past the shard's forward halo");
   // drop placeholders that did not match; verify the demod window of every record was inside the shard
-  Rec* r = (Rec*)c->h_out;
+  Rec* r = (Rec*)c->slot[c->last_slot].h_out;
   int w = 0;
   for (int i = 0; i < nres; ++i) {
     const unsigned fl = (unsigned)(r[i].w[3] >> 48);
@@ -480,7 +551,7 @@ int adsb_shard_device(adsb_ctx* c, int fmt, const void* d_data, int64_t n, int64
     if (off - 100 < origin && origin > 0) return fail(c, -EOVERFLOW, "noise window runs past the shard's back halo");
     r[w++] = r[i];
   }
-  c->last_n = w;
+  c->slot[c->last_slot].nres = w;
   return deliver(c, w, out, cap, n_out);
 }
 

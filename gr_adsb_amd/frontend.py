@@ -59,6 +59,14 @@ class FrontEnd:
         assert t.is_cuda and t.is_contiguous()
         return self.ctx.process_mag2_device(t.data_ptr(), t.shape[0], abs_offset, fetch=fetch)
 
+    def submit_iq_tensor(self, t, abs_offset=0):
+        """Queue a canonical pass over t (two may be in flight); returns a ticket for wait()."""
+        assert t.is_cuda and t.is_contiguous()
+        return self.ctx.submit_iq_device(t.data_ptr(), t.shape[0], abs_offset)
+
+    def wait(self, ticket, fetch=True):
+        return self.ctx.wait(ticket, fetch=fetch)
+
     def shard_tensor(self, t, origin, own_lo, own_hi, stream_len, fmt=0):
         assert t.is_cuda and t.is_contiguous()
         return self.ctx.shard_device(fmt, t.data_ptr(), t.shape[0], origin, own_lo, own_hi, stream_len)

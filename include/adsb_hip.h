@@ -12,6 +12,7 @@
  *   adsb_process_iq[_device]        complex_to_mag_squared -> framer -> demod as wired in
  *                                   examples/adsb_rx.py:180-196 (one canonical work() call per block)
  *   adsb_process_mag2[_device]      the same chain from the framer's float input onwards
+ *   adsb_submit_*_device / adsb_wait   the same, two calls in flight (no reference counterpart: pipelining)
  *   adsb_shard_*_device / adsb_stitch   (no reference counterpart: overlapped time shards, host stitch)
  *
  * Conventions: the caller owns every buffer it passes; the library owns device memory, pinned staging
@@ -90,6 +91,16 @@ int adsb_process_iq_device(adsb_ctx* ctx, const void* d_iq, int64_t n, int64_t a
 int adsb_process_mag2_device(adsb_ctx* ctx, const void* d_mag2, int64_t n, int64_t abs_offset,
                              adsb_burst* out, int32_t cap, int32_t* n_out);
 int adsb_last_result(adsb_ctx* ctx, const adsb_burst** bursts, int32_t* n);
+
+/* Two-deep asynchronous form of adsb_process_*_device: submit queues the whole device pipeline on the
+ * context's compute stream and returns a ticket (0 or 1) at once; adsb_wait blocks for that call, copies
+ * its bursts to pinned host memory on a second stream and delivers them like adsb_process_*.  With call
+ * i+1 submitted before waiting for call i the PCIe copy and all host work of call i overlap the kernels of
+ * call i+1.  The input buffer must stay valid and unchanged until adsb_wait returns.  At most two calls
+ * in flight (-EBUSY otherwise); results must be collected in submission order. */
+int adsb_submit_iq_device(adsb_ctx* ctx, const void* d_iq, int64_t n, int64_t abs_offset, int32_t* ticket);
+int adsb_submit_mag2_device(adsb_ctx* ctx, const void* d_mag2, int64_t n, int64_t abs_offset, int32_t* ticket);
+int adsb_wait(adsb_ctx* ctx, int32_t ticket, adsb_burst* out, int32_t cap, int32_t* n_out);
 
 /* GNU Radio sync-block emulation, framer.work(): in0 holds N + 8*sps - 1 floats of |IQ|^2 (history
  * first), exactly what the scheduler hands the Python block; nitems_written = nitems_written(0).

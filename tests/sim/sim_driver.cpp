@@ -60,8 +60,9 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   if (mode == 0) hipsim::launch(k_detect<0>, grid, kThreads, a);
   else hipsim::launch(k_detect<1>, grid, kThreads, a);
 
-  bool did_long = false;
-  for (;;) {
+  if (mode == 0) hipsim::launch(k_longrun<0>, 3, kThreads, a);
+  else hipsim::launch(k_longrun<1>, 3, kThreads, a);
+  {
     hipsim::launch(k_scan, 1, kThreads, (const int*)blk_count.data(), (const long long*)blk_lastp.data(),
                    (const unsigned*)blk_flags.data(), grid, rec_cap, (const int*)&long_count,
                    (const unsigned long long*)&long_lastp, blk_off.data(), &sum);
@@ -82,14 +83,6 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
                                   orflags, outv.data(), (int)tot);
     else hipsim::launch(k_burst<1>, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum,
                         orflags, outv.data(), (int)tot);
-    if (sum.long_count > 0 && !did_long && !sum.overflow) {
-      did_long = true;
-      int nl = sum.long_count;
-      if (mode == 0) hipsim::launch(k_longrun<0>, nl < 4 ? nl : 4, kThreads, a, nl);
-      else hipsim::launch(k_longrun<1>, nl < 4 ? nl : 4, kThreads, a, nl);
-      continue;
-    }
-    break;
   }
   so->n_rec = sum.n_rec; so->n_kept = sum.n_kept; so->overflow = sum.overflow; so->long_count = sum.long_count;
   so->flags = sum.flags; so->lastp = sum.lastp; so->last_kept = sum.last_kept_p;

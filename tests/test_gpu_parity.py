@@ -109,6 +109,31 @@ def test_device_resident_synthetic_vs_c_oracle(native, torch_mod, fs, bps, log2n
     assert np.array_equal(got2["offset"], got["offset"] + 123456789012)
 
 
+def test_submit_wait_pipeline_matches_blocking_calls(native, torch_mod):
+    """Two passes in flight (adsb_submit_* / adsb_wait) must deliver exactly what the blocking call does."""
+    from gr_adsb_amd import modulator as M
+    n = 1 << 21
+    iqs = [M.synth_iq(n, 2e6, 2000, seed) for seed in (11, 12, 13)]
+    ts = [to_dev(torch_mod, iq) for iq in iqs]
+    ctx = native.Context(2e6, 0.01)
+    want = [ctx.process_iq_device(t.data_ptr(), n, abs_offset=1000 * i) for i, t in enumerate(ts)]
+    t0 = ctx.submit_iq_device(ts[0].data_ptr(), n, 0)
+    t1 = ctx.submit_iq_device(ts[1].data_ptr(), n, 1000)
+    with pytest.raises(native.AdsbError) as e:
+        ctx.submit_iq_device(ts[2].data_ptr(), n, 2000)
+    assert e.value.code == -16          # -EBUSY: both slots in flight
+    with pytest.raises(native.AdsbError):
+        ctx.process_iq_device(ts[2].data_ptr(), n)   # blocking calls refuse while calls are pending
+    got0 = ctx.wait(t0)
+    t2 = ctx.submit_iq_device(ts[2].data_ptr(), n, 2000)
+    got1 = ctx.wait(t1)
+    got2 = ctx.wait(t2)
+    for g, w in zip((got0, got1, got2), want):
+        assert g.tobytes() == w.tobytes()
+    with pytest.raises(native.AdsbError):
+        ctx.wait(t2)                     # nothing pending on that ticket any more
+
+
 def test_mixed_df_low_snr_config(native, torch_mod):
     """BASELINE.json config 5: mixed DF0/4/5/11/16/17 at 3-25 dB over noise 2e-3."""
     from gr_adsb_amd import modulator as M

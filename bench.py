@@ -75,15 +75,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ADSB_BENCH_ONE_GPU=1: debugging aid -- run the N-rank code path with every rank on cuda:0 (gloo only)
+    one_gpu = os.environ.get("ADSB_BENCH_ONE_GPU") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo" if one_gpu else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
     n_gpus = world
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from gr_adsb_amd import _native
+    from gr_adsb_amd import _native, sharding
     from gr_adsb_amd.frontend import FrontEnd, shard_plan
 
     fs = args.fs
@@ -100,11 +104,9 @@ def main():
         iq = gen_stream_blocks(plan["hi"] - plan["lo"], plan["lo"], fs, args.bursts, args.seed, dev)
     torch.cuda.synchronize()
 
-    tails = None
     pending = []          # tickets of submitted, not yet collected passes (N=1: two-deep pipeline)
 
     def step():
-        nonlocal tails
         if n_gpus == 1:
             # submit pass i+1 before collecting pass i: the PCIe copy and host work of one pass overlap the
             # kernels of the next; every pass is collected inside the timed region (drain() below)
@@ -112,42 +114,34 @@ def main():
             if len(pending) == 2:
                 return fe.wait(pending.pop(0), fetch=False)
             return 0
-        cands = fe.shard_tensor(iq, plan["lo"], plan["own_lo"], plan["own_hi"], stream_len)
-        kept = _native.stitch(cands, sps)                      # local gate, fresh state
-        # exchange the 8-byte tail state; fix the head of this shard against the previous shard's tail
-        tail = torch.tensor([int(kept["offset"][-1]) + 63 * sps if len(kept) else -(1 << 60)], dtype=torch.int64)
-        tails = [torch.zeros(1, dtype=torch.int64) for _ in range(n_gpus)]
-        dist.all_gather(tails, tail)
-        if rank > 0:
-            kept = fix_head(cands, kept, int(tails[rank - 1][0]), sps)
+        # N>1: same two-deep pipeline; the host stitch of pass i (two tiny all_gathers) overlaps the GPU pass i+1
+        pending.append(fe.submit_shard_tensor(iq, plan["lo"], plan["own_lo"], plan["own_hi"], stream_len,
+                                              head_cands=sharding.HEAD_CANDS))
+        if len(pending) == 2:
+            return collect_shard(pending.pop(0))
+        return 0
+
+    def collect_shard(ticket):
+        recs = fe.wait(ticket, copy=False)          # view of the pinned result buffer, fixed up in place
+        kept = sharding.finish_shard(recs, sps, rank, ag_int,
+                                     lambda: fe.shard_tensor(iq, plan["lo"], plan["own_lo"], plan["own_hi"], stream_len),
+                                     ag_obj, inplace=True)
         return len(kept)
 
-    def fix_head(cands, kept, eob_in, sps_):
-        """Re-gate the head of the shard with the true incoming eob until the first centre that starts
-        an independent chain (gap > 63*sps and beyond eob_in); behind it the fresh-state result holds."""
-        off = cands["offset"]
-        gate = 63 * sps_
-        head = len(off)
-        for i in range(1, len(off)):
-            if off[i] - off[i - 1] > gate and off[i] > eob_in:
-                head = i
-                break
-        if head == len(off) and len(off):
-            return _native.stitch(cands[off > eob_in], sps_) if (off <= eob_in).any() else kept
-        eob = eob_in
-        keep_idx = []
-        for i in range(head):
-            if off[i] > eob:
-                keep_idx.append(i)
-                eob = int(off[i]) + gate
-        pre = cands[keep_idx]
-        rest = kept[kept["offset"] >= off[head]] if head < len(off) else kept[:0]
-        return np.concatenate([pre, rest])
+    def ag_int(v):
+        out = [torch.zeros(1, dtype=torch.int64) for _ in range(n_gpus)]
+        dist.all_gather(out, torch.tensor([int(v)], dtype=torch.int64))      # 8 bytes per rank, host side (gloo)
+        return [int(t[0]) for t in out]
+
+    def ag_obj(o):
+        out = [None] * n_gpus
+        dist.all_gather_object(out, o)
+        return out
 
     def drain():
         n = 0
         while pending:
-            n = fe.wait(pending.pop(0), fetch=False)
+            n = fe.wait(pending.pop(0), fetch=False) if n_gpus == 1 else collect_shard(pending.pop(0))
         return n
 
     def sync_all():
@@ -164,12 +158,11 @@ def main():
     n_bursts = 0
     for _ in range(args.steps):
         n_bursts = step()
-    if n_gpus == 1:
-        n_bursts = drain()
+    n_bursts = drain()
     sync_all()
     elapsed = time.perf_counter() - t0
     if n_gpus > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     st = fe.stats()
@@ -200,7 +193,7 @@ def main():
                             % (fs / 1e6, args.bursts, args.threshold, args.log2n),
                 "fs": fs, "samples_per_gpu_per_step": n_own, "bursts_per_step_rank0": int(n_bursts),
                 "sharding": "none" if n_gpus == 1 else "%d overlapped time shards, host stitch" % n_gpus,
-                "pipeline": "2 passes in flight (submit/wait)" if n_gpus == 1 else "blocking",
+                "pipeline": "2 passes in flight (submit/wait)",
                 "detect_grid": int(st["detect_grid"]), "retries": int(st["retries"]), "longrun_calls": int(st["longrun_calls"]),
             },
             "roofline": {

@@ -21,8 +21,8 @@ BURST_KEPT = 2
 EXPORTS = [
     "adsb_abi_version", "adsb_create", "adsb_destroy", "adsb_set_threshold", "adsb_set_stream", "adsb_reset",
     "adsb_process_iq", "adsb_process_mag2", "adsb_process_iq_device", "adsb_process_mag2_device", "adsb_last_result",
-    "adsb_submit_iq_device", "adsb_submit_mag2_device", "adsb_wait",
-    "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_stitch", "adsb_snr_db", "adsb_get_stats",
+    "adsb_submit_iq_device", "adsb_submit_mag2_device", "adsb_submit_shard_device", "adsb_wait",
+    "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_get_stats",
     "adsb_reset_stats", "adsb_last_error",
 ]
 
@@ -76,9 +76,11 @@ def load():
     lib.adsb_submit_iq_device.argtypes = [vp, vp, i64, i64, c.POINTER(i32)]
     lib.adsb_submit_mag2_device.argtypes = [vp, vp, i64, i64, c.POINTER(i32)]
     lib.adsb_wait.argtypes = [vp, i32, vp, i32, c.POINTER(i32)]
+    lib.adsb_submit_shard_device.argtypes = [vp, c.c_int, vp, i64, i64, i64, i64, i64, i32, c.POINTER(i32)]
     lib.adsb_framer_work.argtypes = [vp, vp, i64, i64, i64, vp, i32, c.POINTER(i32)]
     lib.adsb_demod_work.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp, vp]
-    lib.adsb_shard_device.argtypes = [vp, c.c_int, vp, i64, i64, i64, i64, i64, vp, i32, c.POINTER(i32)]
+    lib.adsb_shard_device.argtypes = [vp, c.c_int, vp, i64, i64, i64, i64, i64, i32, vp, i32, c.POINTER(i32)]
+    lib.adsb_shard_fixup.argtypes = [vp, i32, c.c_int, i64, c.POINTER(i32)]
     lib.adsb_stitch.argtypes = [vp, i32, c.c_int, c.POINTER(i32)]
     lib.adsb_snr_db.argtypes = [f32, f32]
     lib.adsb_snr_db.restype = f32
@@ -132,14 +134,17 @@ class Context:
         self._chk(fn(self._h, ctypes.c_void_p(ptr), int(n), int(abs_offset), None, 0, ctypes.byref(n_out)))
         return self.last_result()
 
-    def last_result(self):
+    def last_result(self, copy=True):
+        """Bursts of the last finished call.  copy=False returns a writable view of the context's pinned
+        buffer, valid until the same pipeline slot is used again (two calls later)."""
         p = ctypes.c_void_p()
         n = ctypes.c_int32(0)
         self._chk(self.lib.adsb_last_result(self._h, ctypes.byref(p), ctypes.byref(n)))
         if n.value == 0:
             return np.zeros(0, dtype=BURST_DTYPE)
         buf = (ctypes.c_char * (n.value * 32)).from_address(p.value)
-        return np.frombuffer(buf, dtype=BURST_DTYPE).copy()
+        v = np.frombuffer(buf, dtype=BURST_DTYPE)
+        return v.copy() if copy else v
 
     def process_iq(self, iq, abs_offset=0):
         iq = np.ascontiguousarray(iq, dtype=np.complex64)
@@ -171,10 +176,16 @@ class Context:
         self._chk(self.lib.adsb_submit_mag2_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(n), int(abs_offset), ctypes.byref(t)))
         return t.value
 
-    def wait(self, ticket, fetch=True):
+    def submit_shard_device(self, fmt, dev_ptr, n, origin, own_lo, own_hi, stream_len, head_cands=0):
+        t = ctypes.c_int32(-1)
+        self._chk(self.lib.adsb_submit_shard_device(self._h, int(fmt), ctypes.c_void_p(int(dev_ptr)), int(n), int(origin),
+                                                    int(own_lo), int(own_hi), int(stream_len), int(head_cands), ctypes.byref(t)))
+        return t.value
+
+    def wait(self, ticket, fetch=True, copy=True):
         n_out = ctypes.c_int32(0)
         self._chk(self.lib.adsb_wait(self._h, int(ticket), None, 0, ctypes.byref(n_out)))
-        return self.last_result() if fetch else n_out.value
+        return self.last_result(copy=copy) if fetch else n_out.value
 
     def framer_work(self, in0, N, nitems_written):
         in0 = np.ascontiguousarray(in0, dtype=np.float32)
@@ -196,10 +207,10 @@ class Context:
                                            ctypes.c_void_p(ratio.ctypes.data) if want_ratio else None))
         return bits, ok.astype(bool), ratio
 
-    def shard_device(self, fmt, dev_ptr, n, origin, own_lo, own_hi, stream_len):
+    def shard_device(self, fmt, dev_ptr, n, origin, own_lo, own_hi, stream_len, head_cands=0):
         n_out = ctypes.c_int32(0)
         self._chk(self.lib.adsb_shard_device(self._h, int(fmt), ctypes.c_void_p(int(dev_ptr)), int(n), int(origin), int(own_lo),
-                                             int(own_hi), int(stream_len), None, 0, ctypes.byref(n_out)))
+                                             int(own_hi), int(stream_len), int(head_cands), None, 0, ctypes.byref(n_out)))
         return self.last_result()
 
     def stats(self):
@@ -220,6 +231,36 @@ def stitch(cands, sps):
     if rc != 0:
         raise AdsbError(rc, "adsb_stitch")
     return cands[:nk.value]
+
+
+BURST_HEAD = 16
+EOB_NONE = -(1 << 60)
+
+
+def shard_fixup(recs, sps, eob_in, inplace=False):
+    """Exact kept list of a gated shard (adsb_shard_device head_cands > 0) given the previous shard's tail.
+    Returns None when the head region was too short (-EAGAIN).  inplace=True compacts recs itself (e.g. a
+    last_result(copy=False) view of the pinned buffer) instead of a copy."""
+    lib = load()
+    if not inplace:
+        recs = np.ascontiguousarray(recs, dtype=BURST_DTYPE).copy()
+    assert recs.dtype == BURST_DTYPE and recs.flags.c_contiguous
+    nk = ctypes.c_int32(0)
+    rc = lib.adsb_shard_fixup(ctypes.c_void_p(recs.ctypes.data), len(recs), int(sps), int(eob_in), ctypes.byref(nk))
+    if rc == -11:
+        return None
+    if rc != 0:
+        raise AdsbError(rc, "adsb_shard_fixup")
+    return recs[:nk.value]
+
+
+def shard_tail(recs, sps):
+    """End-of-burst state a gated shard hands to the next one."""
+    fl = recs["flags"]
+    for i in range(len(recs) - 1, -1, -1):          # behind the head region every record is KEPT: O(1) in practice
+        if fl[i] & BURST_KEPT:
+            return int(recs["offset"][i]) + 63 * sps
+    return EOB_NONE
 
 
 def snr_db_c(peak, median):

@@ -59,6 +59,7 @@ enum RecFlags : unsigned {
   kKept = 2u,      // passed the re-trigger gate (framer.py:121)
   kNoMatch = 4u,   // placeholder whose long pulse did not match the preamble
   kPending = 8u,   // placeholder waiting for k_longrun
+  kHead = 16u,     // shard mode: one of the first centres of the shard, delivered whether gated or not
 };
 
 // 32-byte burst record: w0 = stream offset (int64); w1 = peak | median<<32 (float bits);
@@ -162,7 +163,7 @@ __device__ __forceinline__ float key_f32(unsigned k) {
 }
 
 template <int MODE>
-__device__ void emit_record(const DetectArgs& a, long long p, Rec* out, int lane) {
+__device__ void emit_record(const DetectArgs& a, long long p, unsigned xflags, Rec* out, int lane) {
   const void* d = a.data;
   const long long n = a.n;
   const int sps = a.sps, half = sps >> 1;
@@ -215,7 +216,7 @@ __device__ void emit_record(const DetectArgs& a, long long p, Rec* out, int lane
   if (lane == 0) {
     const unsigned long long ra = __builtin_bswap64(__brevll(ma));
     const unsigned long long rb = __builtin_bswap64(__brevll(mb)) & 0xFFFFFFFFFFFFull;
-    const unsigned flags = dem ? kDemod : 0u;
+    const unsigned flags = (dem ? kDemod : 0u) | xflags;
     Rec r;
     r.w[0] = (unsigned long long)(a.origin + p);
     r.w[1] = (unsigned long long)__builtin_bit_cast(unsigned, peak) |
@@ -683,17 +684,24 @@ __global__ void __launch_bounds__(kThreads) k_resolve(unsigned long long* sorted
 }
 
 // ---- k_count / k_scan2 / k_compact: survivors -> dense list ------------------------------------------
-// A word survives when (flags & fmask) == fwant: gate on -> (kKept, kKept); gate off (shards) -> every
-// real centre: (kNoMatch | kPending, 0).
+// A real centre survives when (flags & fmask) == fwant -- gate on: (kKept, kKept); gate off: (0, 0) -- or
+// when it is one of the first head_n entries of the list (shard mode: the head of a shard is delivered
+// whole so that the host can re-gate it against the previous shard's tail).
+__device__ __forceinline__ bool survives(unsigned long long c, int i, unsigned fmask, unsigned fwant, int head_n) {
+  const unsigned f = cand_flags(c);
+  if (f & (kNoMatch | kPending)) return false;
+  return (f & fmask) == fwant || i < head_n;
+}
+
 __global__ void __launch_bounds__(kThreads) k_count(const unsigned long long* sorted, const Summary* sum,
-                                                    unsigned fmask, unsigned fwant, int* seg_count) {
+                                                    unsigned fmask, unsigned fwant, int head_n, int* seg_count) {
   __shared__ int s_c[kWaves];
   const int n = sum->n_rec;
   const int nseg = (n + kThreads - 1) / kThreads;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const int i = seg * kThreads + threadIdx.x;
-    const bool kept = i < n && (cand_flags(sorted[i]) & fmask) == fwant;
+    const bool kept = i < n && survives(sorted[i], i, fmask, fwant, head_n);
     const unsigned long long m = __ballot(kept);
     if (lane == 0) s_c[wave] = __popcll(m);
     __syncthreads();
@@ -726,7 +734,7 @@ __global__ void __launch_bounds__(kThreads) k_scan2(int* seg_count, Summary* sum
 }
 
 __global__ void __launch_bounds__(kThreads) k_compact(const unsigned long long* sorted, Summary* sum,
-                                                      const int* seg_off, unsigned fmask, unsigned fwant,
+                                                      const int* seg_off, unsigned fmask, unsigned fwant, int head_n,
                                                       unsigned long long* kept, int out_cap) {
   __shared__ int s_c[kWaves];
   const int n = sum->n_rec;
@@ -734,8 +742,9 @@ __global__ void __launch_bounds__(kThreads) k_compact(const unsigned long long* 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const int i = seg * kThreads + threadIdx.x;
-    const unsigned long long c = (i < n) ? sorted[i] : 0ull;
-    const bool k = i < n && (cand_flags(c) & fmask) == fwant;
+    unsigned long long c = (i < n) ? sorted[i] : 0ull;
+    const bool k = i < n && survives(c, i, fmask, fwant, head_n);
+    if (i < head_n) c |= (unsigned long long)kHead << 56;
     const unsigned long long m = __ballot(k);
     if (lane == 0) s_c[wave] = __popcll(m);
     __syncthreads();
@@ -753,15 +762,15 @@ __global__ void __launch_bounds__(kThreads) k_compact(const unsigned long long* 
 // ---- k_burst: one wavefront per surviving centre -> the 32-byte burst record -------------------------
 template <int MODE>
 __global__ void __launch_bounds__(kThreads) k_burst(DetectArgs a, const unsigned long long* kept, const Summary* sum,
-                                                    unsigned orflags, Rec* out, int out_cap) {
+                                                    Rec* out, int out_cap) {
   const int lane = threadIdx.x & 63;
   const int wave_g = (int)((blockIdx.x * (unsigned)kThreads + threadIdx.x) >> 6);
   const int nwave = (int)((gridDim.x * (unsigned)kThreads) >> 6);
   int n = sum->n_kept;
   if (n > out_cap) n = out_cap;
   for (int t = wave_g; t < n; t += nwave) {
-    emit_record<MODE>(a, cand_p(kept[t]), out + t, lane);
-    if (lane == 0 && orflags) out[t].w[3] |= (unsigned long long)orflags << 48;
+    const unsigned long long c = kept[t];
+    emit_record<MODE>(a, cand_p(c), cand_flags(c) & (kKept | kHead), out + t, lane);
   }
 }
 

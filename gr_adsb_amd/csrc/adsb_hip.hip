@@ -54,6 +54,7 @@ struct Slot {
   size_t h_out_cap = 0;
   hipEvent_t done = nullptr, ev0 = nullptr, ev1 = nullptr;
   bool busy = false;
+  bool is_shard = false;
   Plan plan{};
   DetectArgs args{};
   int grid = 0, rec_cap = 0;
@@ -127,9 +128,8 @@ void launch_detect(adsb_ctx* c, const DetectArgs& a, int grid) {
   hipLaunchKernelGGL((k_detect<MODE>), dim3(grid), dim3(kThreads), dyn, c->stream, a);
 }
 template <int MODE>
-void launch_burst(adsb_ctx* c, const DetectArgs& a, const unsigned long long* kept, const Summary* sum, unsigned orflags,
-                  Rec* out, int cap) {
-  hipLaunchKernelGGL((k_burst<MODE>), dim3(c->n_cu * 8), dim3(kThreads), 0, c->stream, a, kept, sum, orflags, out, cap);
+void launch_burst(adsb_ctx* c, const DetectArgs& a, const unsigned long long* kept, const Summary* sum, Rec* out, int cap) {
+  hipLaunchKernelGGL((k_burst<MODE>), dim3(c->n_cu * 8), dim3(kThreads), 0, c->stream, a, kept, sum, out, cap);
 }
 template <int MODE>
 void launch_longrun(adsb_ctx* c, const DetectArgs& a) {
@@ -150,19 +150,19 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   hipLaunchKernelGGL(k_gather, dim3(gg), dim3(kThreads), 0, c->stream, (const unsigned long long*)a.cands,
                      (const int*)a.blk_count, (const int*)s.d_blk_off.p, s.grid, s.rec_cap, sorted);
   const int ag = 512;
-  unsigned fmask = kNoMatch | kPending, fwant = 0u, orflags = 0u;
+  unsigned fmask = 0u, fwant = 0u;
   if (pl.gate) {
     hipLaunchKernelGGL(k_resolve, dim3(ag), dim3(kThreads), 0, c->stream, sorted, (const Summary*)&misc->sum,
                        (long long)63 * c->sps, pl.prev_eob_stream - pl.origin);
-    fmask = kKept; fwant = kKept; orflags = kKept;
+    fmask = kKept; fwant = kKept;
   }
   hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, c->stream, (const unsigned long long*)sorted,
-                     (const Summary*)&misc->sum, fmask, fwant, (int*)s.d_seg.p);
+                     (const Summary*)&misc->sum, fmask, fwant, pl.head_n, (int*)s.d_seg.p);
   hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kThreads), 0, c->stream, (int*)s.d_seg.p, &misc->sum);
   hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, c->stream, (const unsigned long long*)sorted, &misc->sum,
-                     (const int*)s.d_seg.p, fmask, fwant, kept, (int)s.tot);
-  if (pl.mode == 0) launch_burst<0>(c, a, kept, &misc->sum, orflags, (Rec*)s.d_out.p, (int)s.tot);
-  else launch_burst<1>(c, a, kept, &misc->sum, orflags, (Rec*)s.d_out.p, (int)s.tot);
+                     (const int*)s.d_seg.p, fmask, fwant, pl.head_n, kept, (int)s.tot);
+  if (pl.mode == 0) launch_burst<0>(c, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
+  else launch_burst<1>(c, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
   HIPCHK(c, hipMemcpyAsync(s.h_sum, &misc->sum, sizeof(Summary), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipEventRecord(s.done, c->stream));
   return 0;
@@ -429,6 +429,8 @@ int adsb_process_mag2(adsb_ctx* c, const float* mag2_host, int64_t n, int64_t ab
   return canonical(c, 1, d, n, abs_offset, out, cap, n_out);
 }
 
+static int shard_post(adsb_ctx* c, Slot& s, const Summary& sum, int32_t nres);
+
 static int submit_canonical(adsb_ctx* c, int mode, const void* d_data, int64_t n, int64_t abs_offset, int32_t* ticket) {
   if (!c || n < 1 || !ticket) return -EINVAL;
   if (((uintptr_t)d_data & 15u) != 0) return fail(c, -EINVAL, "device pointer must be 16-byte aligned");
@@ -437,6 +439,7 @@ static int submit_canonical(adsb_ctx* c, int mode, const void* d_data, int64_t n
   Plan pl = plan_canonical(mode, d_data, n, abs_offset, c->sps);
   int r = enqueue(c, s, pl);
   if (r) { s.busy = false; return r; }
+  s.is_shard = false;
   *ticket = c->next_slot;
   c->next_slot ^= 1;
   return 0;
@@ -459,6 +462,7 @@ int adsb_wait(adsb_ctx* c, int32_t ticket, adsb_burst* out, int32_t cap, int32_t
   int r = finish(c, s, &sum, &nres);
   if (r) return r;
   c->last_slot = ticket;
+  if (s.is_shard && (r = shard_post(c, s, sum, nres))) return r;
   return deliver(c, nres, out, cap, n_out);
 }
 
@@ -528,20 +532,11 @@ int adsb_demod_work(adsb_ctx* c, const float* in0, int64_t n, int64_t nitems_rea
   return 0;
 }
 
-int adsb_shard_device(adsb_ctx* c, int fmt, const void* d_data, int64_t n, int64_t origin, int64_t own_lo,
-                      int64_t own_hi, int64_t stream_len, adsb_burst* out, int32_t cap, int32_t* n_out) {
-  if (!c || n < 0 || (fmt != 0 && fmt != 1)) return -EINVAL;
-  if (((uintptr_t)d_data & 15u) != 0) return fail(c, -EINVAL, "device pointer must be 16-byte aligned");
-  Plan pl = plan_shard(fmt, d_data, n, origin, own_lo, own_hi, stream_len, c->sps);
-  if (origin > 0 && pl.scan_lo < 1) return fail(c, -EINVAL, "shard needs at least one sample of back halo");
-  Summary s;
-  int32_t nres = 0;
-  int rc = run_pipeline(c, pl, &s, &nres);
-  if (rc) return rc;
-  if (s.flags & 4u) return fail(c, -EOVERFLOW, "pulse runs past the shard's forward halo");
-  // drop placeholders that did not match; verify the demod window of every record was inside the shard
-  Rec* r = (Rec*)c->slot[c->last_slot].h_out;
-  int w = 0;
+// Halo checks of a finished shard call (the records are in the slot's pinned buffer).
+static int shard_post(adsb_ctx* c, Slot& s, const Summary& sum, int32_t nres) {
+  if (sum.flags & 4u) return fail(c, -EOVERFLOW, "pulse runs past the shard's forward halo");
+  const Rec* r = (const Rec*)s.h_out;
+  const long long origin = s.plan.origin, n = s.plan.n, stream_len = s.plan.origin + s.plan.dem_hi;
   for (int i = 0; i < nres; ++i) {
     const unsigned fl = (unsigned)(r[i].w[3] >> 48);
     const long long off = (long long)r[i].w[0];
@@ -549,10 +544,79 @@ int adsb_shard_device(adsb_ctx* c, int fmt, const void* d_data, int64_t n, int64
     if (!(fl & kDemod) && eob < stream_len) return fail(c, -EOVERFLOW, "internal: demod flag");
     if ((fl & kDemod) && eob >= origin + n) return fail(c, -EOVERFLOW, "burst runs past the shard's forward halo");
     if (off - 100 < origin && origin > 0) return fail(c, -EOVERFLOW, "noise window runs past the shard's back halo");
-    r[w++] = r[i];
   }
-  c->slot[c->last_slot].nres = w;
-  return deliver(c, w, out, cap, n_out);
+  return 0;
+}
+
+static int shard_plan_checked(adsb_ctx* c, int fmt, const void* d_data, int64_t n, int64_t origin, int64_t own_lo,
+                              int64_t own_hi, int64_t stream_len, int32_t head_cands, Plan* pl) {
+  if (!c || n < 0 || (fmt != 0 && fmt != 1) || head_cands < 0) return -EINVAL;
+  if (((uintptr_t)d_data & 15u) != 0) return fail(c, -EINVAL, "device pointer must be 16-byte aligned");
+  *pl = plan_shard(fmt, d_data, n, origin, own_lo, own_hi, stream_len, c->sps, head_cands);
+  if (origin > 0 && pl->scan_lo < 1) return fail(c, -EINVAL, "shard needs at least one sample of back halo");
+  return 0;
+}
+
+int adsb_shard_device(adsb_ctx* c, int fmt, const void* d_data, int64_t n, int64_t origin, int64_t own_lo,
+                      int64_t own_hi, int64_t stream_len, int32_t head_cands, adsb_burst* out, int32_t cap,
+                      int32_t* n_out) {
+  Plan pl;
+  int rc = shard_plan_checked(c, fmt, d_data, n, origin, own_lo, own_hi, stream_len, head_cands, &pl);
+  if (rc) return rc;
+  Summary s;
+  int32_t nres = 0;
+  rc = run_pipeline(c, pl, &s, &nres);
+  if (rc) return rc;
+  if ((rc = shard_post(c, c->slot[c->last_slot], s, nres))) return rc;
+  return deliver(c, nres, out, cap, n_out);
+}
+
+int adsb_submit_shard_device(adsb_ctx* c, int fmt, const void* d_data, int64_t n, int64_t origin, int64_t own_lo,
+                             int64_t own_hi, int64_t stream_len, int32_t head_cands, int32_t* ticket) {
+  if (!ticket) return -EINVAL;
+  Plan pl;
+  int rc = shard_plan_checked(c, fmt, d_data, n, origin, own_lo, own_hi, stream_len, head_cands, &pl);
+  if (rc) return rc;
+  Slot& s = c->slot[c->next_slot];
+  if (s.busy) return fail(c, -EBUSY, "both pipeline slots are in flight (adsb_wait first)");
+  rc = enqueue(c, s, pl);
+  if (rc) { s.busy = false; return rc; }
+  s.is_shard = true;
+  *ticket = c->next_slot;
+  c->next_slot ^= 1;
+  return 0;
+}
+
+int adsb_shard_fixup(adsb_burst* recs, int32_t n, int sps, int64_t eob_in, int32_t* n_kept) {
+  // recs: output of adsb_shard_device(head_cands > 0): every centre of the shard's head (ADSB_BURST_HEAD,
+  // complete, gated or not) followed by the centres a fresh-state gate kept.  Re-gate the head with the
+  // true incoming eob (framer.py:121-123,165) until the first centre that starts an independent chain
+  // -- more than 63*sps after its predecessor and beyond eob_in: it is accepted whatever came before, so
+  // from there on the fresh-state decisions are exact.
+  if (n < 0 || (n > 0 && !recs) || sps < 2 || !n_kept) return -EINVAL;
+  const long long gate = 63ll * sps;
+  int i = 0, w = 0;
+  long long eob = eob_in;
+  bool synced = false;
+  for (; i < n && (recs[i].flags & ADSB_BURST_HEAD); ++i) {
+    const long long p = recs[i].offset;
+    if (i > 0 && p - recs[i - 1].offset > gate && p > eob_in) { synced = true; break; }
+    if (p > eob) {
+      eob = p + gate;
+      adsb_burst b = recs[i];
+      b.flags = (uint16_t)((b.flags | ADSB_BURST_KEPT) & ~ADSB_BURST_HEAD);
+      recs[w++] = b;
+    }
+  }
+  if (!synced && i < n) return -EAGAIN;   // the head region ended inside a chain: ask for a larger head
+  for (; i < n; ++i) {
+    if (!(recs[i].flags & ADSB_BURST_KEPT)) continue;
+    adsb_burst b = recs[i];
+    b.flags = (uint16_t)(b.flags & ~ADSB_BURST_HEAD);
+    recs[w++] = b;
+  }
+  *n_kept = w;
+  return 0;
 }
 
 int adsb_stitch(adsb_burst* cands, int32_t n, int sps, int32_t* n_kept) {

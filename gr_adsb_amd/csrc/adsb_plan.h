@@ -21,6 +21,7 @@ struct Plan {
   int end_is_call_end;
   long long prev_eob_stream;    // framer.py:57 expressed as a stream offset
   bool gate;                // apply framer.py:121-123 on the device
+  int head_n = 0;           // shard mode: deliver the first head_n centres whether gated or not
 };
 
 struct FramerState {
@@ -73,7 +74,7 @@ inline void framer_state_update(FramerState& st, float last_sample, long long N,
 // One overlapped time shard of a canonical whole-stream call.  The buffer holds stream samples
 // [origin, origin+n); this shard owns rises with stream offset in [own_lo, own_hi).
 inline Plan plan_shard(int mode, const void* d, long long n, long long origin, long long own_lo, long long own_hi,
-                       long long stream_len, int sps) {
+                       long long stream_len, int sps, int head_n = 0) {
   const long long H = 8ll * sps;
   const long long scan_end = stream_len - (H - 1);       // framer scans stream offsets [-(H-1), stream_len-(H-1))
   Plan p;
@@ -90,8 +91,10 @@ inline Plan plan_shard(int mode, const void* d, long long n, long long origin, l
   p.dem_hi = stream_len - origin;
   p.prev_in0 = 0.0f;
   p.prev_eob_stream = -(1ll << 61);
-  p.gate = false;
+  p.gate = head_n > 0;                                   // gated with fresh state + whole head, or not gated at all
+  p.head_n = head_n;
   return p;
 }
 
 }  // namespace adsb
+

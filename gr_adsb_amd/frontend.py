@@ -64,12 +64,16 @@ class FrontEnd:
         assert t.is_cuda and t.is_contiguous()
         return self.ctx.submit_iq_device(t.data_ptr(), t.shape[0], abs_offset)
 
-    def wait(self, ticket, fetch=True):
-        return self.ctx.wait(ticket, fetch=fetch)
-
-    def shard_tensor(self, t, origin, own_lo, own_hi, stream_len, fmt=0):
+    def submit_shard_tensor(self, t, origin, own_lo, own_hi, stream_len, fmt=0, head_cands=0):
         assert t.is_cuda and t.is_contiguous()
-        return self.ctx.shard_device(fmt, t.data_ptr(), t.shape[0], origin, own_lo, own_hi, stream_len)
+        return self.ctx.submit_shard_device(fmt, t.data_ptr(), t.shape[0], origin, own_lo, own_hi, stream_len, head_cands)
+
+    def wait(self, ticket, fetch=True, copy=True):
+        return self.ctx.wait(ticket, fetch=fetch, copy=copy)
+
+    def shard_tensor(self, t, origin, own_lo, own_hi, stream_len, fmt=0, head_cands=0):
+        assert t.is_cuda and t.is_contiguous()
+        return self.ctx.shard_device(fmt, t.data_ptr(), t.shape[0], origin, own_lo, own_hi, stream_len, head_cands)
 
     def stitch(self, cand_lists):
         c = np.concatenate([np.asarray(x, dtype=_native.BURST_DTYPE) for x in cand_lists]) if len(cand_lists) else \

@@ -13,7 +13,7 @@
  *                                   examples/adsb_rx.py:180-196 (one canonical work() call per block)
  *   adsb_process_mag2[_device]      the same chain from the framer's float input onwards
  *   adsb_submit_*_device / adsb_wait   the same, two calls in flight (no reference counterpart: pipelining)
- *   adsb_shard_*_device / adsb_stitch   (no reference counterpart: overlapped time shards, host stitch)
+ *   adsb_shard_device / adsb_shard_fixup / adsb_stitch   (no reference counterpart: overlapped time shards, host stitch)
  *
  * Conventions: the caller owns every buffer it passes; the library owns device memory, pinned staging
  * and one HIP stream per context.  A context is single-threaded; different contexts may be used
@@ -38,6 +38,7 @@ extern "C" {
 /* adsb_burst.flags */
 #define ADSB_BURST_DEMOD 1u /* eob inside the demod input: bits[] valid, a PDU is published (demod.py:82) */
 #define ADSB_BURST_KEPT 2u  /* passed the framer's re-trigger gate (framer.py:121) */
+#define ADSB_BURST_HEAD 16u /* shard mode: part of the shard's head region (see adsb_shard_device) */
 
 typedef struct adsb_ctx adsb_ctx;
 
@@ -100,6 +101,8 @@ int adsb_last_result(adsb_ctx* ctx, const adsb_burst** bursts, int32_t* n);
  * in flight (-EBUSY otherwise); results must be collected in submission order. */
 int adsb_submit_iq_device(adsb_ctx* ctx, const void* d_iq, int64_t n, int64_t abs_offset, int32_t* ticket);
 int adsb_submit_mag2_device(adsb_ctx* ctx, const void* d_mag2, int64_t n, int64_t abs_offset, int32_t* ticket);
+int adsb_submit_shard_device(adsb_ctx* ctx, int fmt, const void* d_data, int64_t n, int64_t origin, int64_t own_lo,
+                             int64_t own_hi, int64_t stream_len, int32_t head_cands, int32_t* ticket);
 int adsb_wait(adsb_ctx* ctx, int32_t ticket, adsb_burst* out, int32_t cap, int32_t* n_out);
 
 /* GNU Radio sync-block emulation, framer.work(): in0 holds N + 8*sps - 1 floats of |IQ|^2 (history
@@ -120,12 +123,21 @@ int adsb_demod_work(adsb_ctx* ctx, const float* in0, int64_t n, int64_t nitems_r
 
 /* Overlapped time shards (multi-GPU): the device buffer holds stream samples [origin, origin+n) of
  * which this shard owns the pulse rises in [own_lo, own_hi) (stream offsets).  stream_len = length of
- * the whole stream (for the end-of-stream rules); fmt 0 = complex64, 1 = float |IQ|^2.  Returns every matched
- * preamble centre of the owned range, NOT gated (flags never has KEPT); adsb_stitch applies the gate
- * over the concatenation.  -EOVERFLOW when a pulse runs past the shard's forward halo. */
+ * the whole stream (for the end-of-stream rules); fmt 0 = complex64, 1 = float |IQ|^2.
+ *   head_cands == 0: returns EVERY matched preamble centre of the owned range, not gated (KEPT never
+ *     set); adsb_stitch applies the gate over the concatenation of all shards.
+ *   head_cands  > 0: the gate runs on the device as if the shard started a fresh stream (KEPT set), and
+ *     the first head_cands centres of the shard are returned whether gated or not (HEAD set): with the
+ *     previous shard's end-of-burst state adsb_shard_fixup then makes the result exact on the host, so
+ *     ranks exchange 8 bytes instead of candidate lists.
+ * -EOVERFLOW when a pulse or burst runs past the shard's halo. */
 int adsb_shard_device(adsb_ctx* ctx, int fmt, const void* d_data, int64_t n, int64_t origin,
-                      int64_t own_lo, int64_t own_hi, int64_t stream_len,
+                      int64_t own_lo, int64_t own_hi, int64_t stream_len, int32_t head_cands,
                       adsb_burst* out, int32_t cap, int32_t* n_out);
+/* eob_in = (offset of the last burst kept before this shard) + 63*sps, or a very negative number for the
+ * first shard.  Compacts recs in place to the exact kept list; -EAGAIN if the head region was too short
+ * (call adsb_shard_device again with a larger head_cands, or with 0 and adsb_stitch). */
+int adsb_shard_fixup(adsb_burst* recs, int32_t n, int sps, int64_t eob_in, int32_t* n_kept);
 /* Host stitch: cands = shard outputs concatenated in stream order; applies the re-trigger gate
  * (framer.py:121-123,165) in place (sets KEPT) and compacts the kept bursts to the front. */
 int adsb_stitch(adsb_burst* cands, int32_t n, int sps, int32_t* n_kept);

@@ -22,7 +22,7 @@ struct SimOut {
 // mode 0: data = complex64 (2n floats); mode 1: data = float |IQ|^2.  Returns 0 or -1 (overflow of out).
 int sim_run(int mode, const float* data, long long n, long long in0_base, long long scan_lo, long long scan_hi,
             long long fall_hi, long long dem_hi, long long origin, float thr, float prev_in0, int sps,
-            int end_is_call_end, long long prev_eob_stream, int gate, int grid_max, int rec_cap_in,
+            int end_is_call_end, long long prev_eob_stream, int gate, int head_n, int grid_max, int rec_cap_in,
             unsigned long long* out_recs /* 4 words each */, int out_cap, SimOut* so) {
   const long long span = scan_hi > 0 ? scan_hi : 0;
   long long ntiles = (span + kTile - 1) / kTile;
@@ -68,21 +68,21 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
                    (const unsigned long long*)&long_lastp, blk_off.data(), &sum);
     hipsim::launch(k_gather, grid < 8 ? grid : 8, kThreads, (const unsigned long long*)cands.data(),
                    (const int*)blk_count.data(), (const int*)blk_off.data(), grid, rec_cap, sorted.data());
-    unsigned fmask = kNoMatch | kPending, fwant = 0u, orflags = 0u;
+    unsigned fmask = 0u, fwant = 0u;
     if (gate) {
       hipsim::launch(k_resolve, 3, kThreads, sorted.data(), (const Summary*)&sum, (long long)63 * sps,
                      prev_eob_stream - origin);
-      fmask = kKept; fwant = kKept; orflags = kKept;
+      fmask = kKept; fwant = kKept;
     }
     hipsim::launch(k_count, 3, kThreads, (const unsigned long long*)sorted.data(), (const Summary*)&sum, fmask, fwant,
-                   seg.data());
+                   head_n, seg.data());
     hipsim::launch(k_scan2, 1, kThreads, seg.data(), &sum);
     hipsim::launch(k_compact, 3, kThreads, (const unsigned long long*)sorted.data(), &sum, (const int*)seg.data(),
-                   fmask, fwant, kept.data(), (int)tot);
+                   fmask, fwant, head_n, kept.data(), (int)tot);
     if (mode == 0) hipsim::launch(k_burst<0>, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum,
-                                  orflags, outv.data(), (int)tot);
+                                  outv.data(), (int)tot);
     else hipsim::launch(k_burst<1>, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum,
-                        orflags, outv.data(), (int)tot);
+                        outv.data(), (int)tot);
   }
   so->n_rec = sum.n_rec; so->n_kept = sum.n_kept; so->overflow = sum.overflow; so->long_count = sum.long_count;
   so->flags = sum.flags; so->lastp = sum.lastp; so->last_kept = sum.last_kept_p;
@@ -99,7 +99,7 @@ int sim_canonical(int mode, const float* data, long long n, long long abs_offset
                   int rec_cap, unsigned long long* out, int out_cap, SimOut* so) {
   Plan p = plan_canonical(mode, data, n, abs_offset, sps);
   return sim_run(mode, data, n, p.in0_base, p.scan_lo, p.scan_hi, p.fall_hi, p.dem_hi, p.origin, thr, p.prev_in0, sps,
-                 p.end_is_call_end, p.prev_eob_stream, 1, grid_max, rec_cap, out, out_cap, so);
+                 p.end_is_call_end, p.prev_eob_stream, 1, 0, grid_max, rec_cap, out, out_cap, so);
 }
 
 // state[0] = prev_in0 (float bits in a double), state[1] = prev_eob
@@ -110,7 +110,7 @@ int sim_framer_work(const float* in0, long long n_in0, long long N, long long ni
   st.prev_in0 = *prev_in0; st.prev_eob = *prev_eob;
   Plan p = plan_framer_work(in0, n_in0, N, nitems_written, sps, st);
   int rc = sim_run(1, in0, n_in0, p.in0_base, p.scan_lo, p.scan_hi, p.fall_hi, p.dem_hi, p.origin, thr, p.prev_in0, sps,
-                   p.end_is_call_end, p.prev_eob_stream, 1, grid_max, 0, out, out_cap, so);
+                   p.end_is_call_end, p.prev_eob_stream, 1, 0, grid_max, 0, out, out_cap, so);
   if (rc) return rc;
   framer_state_update(st, in0[N - 1], N, sps, so->flags, so->lastp, kNoIndex, so->n_kept,
                       so->n_kept > 0 ? so->last_kept : 0);
@@ -119,10 +119,11 @@ int sim_framer_work(const float* in0, long long n_in0, long long N, long long ni
 }
 
 int sim_shard(int mode, const float* data, long long n, long long origin, long long own_lo, long long own_hi,
-              long long stream_len, float thr, int sps, int grid_max, unsigned long long* out, int out_cap, SimOut* so) {
-  Plan p = plan_shard(mode, data, n, origin, own_lo, own_hi, stream_len, sps);
+              long long stream_len, float thr, int sps, int head_n, int grid_max, unsigned long long* out, int out_cap,
+              SimOut* so) {
+  Plan p = plan_shard(mode, data, n, origin, own_lo, own_hi, stream_len, sps, head_n);
   return sim_run(mode, data, n, p.in0_base, p.scan_lo, p.scan_hi, p.fall_hi, p.dem_hi, p.origin, thr, p.prev_in0, sps,
-                 p.end_is_call_end, p.prev_eob_stream, 0, grid_max, 0, out, out_cap, so);
+                 p.end_is_call_end, p.prev_eob_stream, p.gate ? 1 : 0, p.head_n, grid_max, 0, out, out_cap, so);
 }
 
 // k_slice for a tag list (demod block emulation)

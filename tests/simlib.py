@@ -56,7 +56,7 @@ def sim_run(mode, data, sps, thr, in0_base, scan_lo, scan_hi, fall_hi, dem_hi, o
     rc = lib().sim_run(c.c_int(mode), data.ctypes.data_as(c.c_void_p), c.c_longlong(n), c.c_longlong(in0_base),
                        c.c_longlong(scan_lo), c.c_longlong(scan_hi), c.c_longlong(fall_hi), c.c_longlong(dem_hi),
                        c.c_longlong(origin), c.c_float(thr), c.c_float(prev_in0), c.c_int(sps), c.c_int(end_is_call_end),
-                       c.c_longlong(prev_eob_stream), c.c_int(1 if gate else 0), c.c_int(grid_max), c.c_int(rec_cap),
+                       c.c_longlong(prev_eob_stream), c.c_int(1 if gate else 0), c.c_int(0), c.c_int(grid_max), c.c_int(rec_cap),
                        out.ctypes.data_as(c.c_void_p), c.c_int(cap), c.byref(so))
     assert rc == 0
     return out[:so.n_kept].copy(), so
@@ -96,12 +96,12 @@ class SimFramer:
         return _call(lib().sim_framer_work, args, max(16, len(in0) // 2 + 16))
 
 
-def sim_shard(mode, data, origin, own_lo, own_hi, stream_len, fs, thr, grid_max=6):
+def sim_shard(mode, data, origin, own_lo, own_hi, stream_len, fs, thr, head_cands=0, grid_max=6):
     c = ctypes
     data = np.ascontiguousarray(data, dtype=np.complex64 if mode == 0 else np.float32)
     args = (c.c_int(mode), data.ctypes.data_as(c.c_void_p), c.c_longlong(len(data)), c.c_longlong(origin),
             c.c_longlong(own_lo), c.c_longlong(own_hi), c.c_longlong(stream_len), c.c_float(thr), c.c_int(int(fs // 1e6)),
-            c.c_int(grid_max))
+            c.c_int(head_cands), c.c_int(grid_max))
     return _call(lib().sim_shard, args, max(16, len(data) // 2 + 16), gate=False)
 
 

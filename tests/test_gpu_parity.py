@@ -201,6 +201,24 @@ def test_overlapped_shards_stitch_equals_single_call(native, torch_mod, fs, bps,
     assert_recs_equal(got, C.process_iq(iq, sps, 0.01), "stitched")
     whole = fe.process_iq_tensor(t)
     assert_recs_equal(got, whole, "stitched vs whole")
+    # gated shards + 8-byte tail exchange + host fix-up of each shard's head (what bench.py --gpus N runs)
+    from gr_adsb_amd import sharding
+    plans = shard_plan(n, shards, sps)
+    bufs = [t[p["lo"]:p["hi"]].contiguous() for p in plans]
+    tickets, parts = [], []
+    for p, b in zip(plans, bufs):       # two in flight, collected in order
+        tickets.append(fe.submit_shard_tensor(b, p["lo"], p["own_lo"], p["own_hi"], n, head_cands=sharding.HEAD_CANDS))
+        if len(tickets) == 2:
+            parts.append(fe.wait(tickets.pop(0)))
+    while tickets:
+        parts.append(fe.wait(tickets.pop(0)))
+    tails = [native.shard_tail(r, sps) for r in parts]
+    outs = [native.shard_fixup(r, sps, sharding.incoming_eob(tails, g)) for g, r in enumerate(parts)]
+    assert all(o is not None for o in outs)
+    fixed = np.concatenate(outs)
+    assert np.array_equal(fixed["offset"], whole["offset"]) and np.array_equal(fixed["bits"], whole["bits"])
+    assert np.array_equal(fixed["median"].view(np.uint32), whole["median"].view(np.uint32))
+    assert np.array_equal(fixed["flags"] & 3, whole["flags"] & 3)
 
 
 def test_full_size_properties(native, torch_mod):

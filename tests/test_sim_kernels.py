@@ -124,3 +124,26 @@ def test_noise_window_at_stream_start_and_nan_median_bits():
         recs, _ = simlib.sim_canonical(1, x, fs, 0.01)
         assert len(want) == 1
         assert_recs_equal(recs, want, "lead %d" % lead)
+
+
+@pytest.mark.parametrize("fs,bps,shards,head", [(2e6, 8000, 4, 64), (2e6, 8000, 4, 2), (20e6, 3000, 3, 16), (2e6, 30000, 5, 8)])
+def test_gated_shards_with_head_fixup_equal_single_call(fs, bps, shards, head):
+    """adsb_shard_device(head_cands > 0) semantics: device gate with fresh state + ungated head region, then
+    the host fix-up with the previous shard's 8-byte tail (gr_adsb_amd.sharding)."""
+    from gr_adsb_amd import _native, sharding
+    from gr_adsb_amd.frontend import shard_plan
+    n = 1 << 17
+    iq = M.synth_iq(n, fs, bps, seed=8)
+    sps = int(fs // 1e6)
+    want = C.canonical(O.mag2(iq), sps, 0.01)
+    plans = shard_plan(n, shards, sps)
+    parts = [simlib.sim_shard(0, iq[p["lo"]:p["hi"]], p["lo"], p["own_lo"], p["own_hi"], n, fs, 0.01, head_cands=head)[0]
+             for p in plans]
+    tails = [_native.shard_tail(r, sps) for r in parts]
+    outs = []
+    for g, r in enumerate(parts):
+        k = _native.shard_fixup(r, sps, sharding.incoming_eob(tails, g))
+        assert k is not None, "head region too short for this fixture"
+        assert not np.any(k["flags"] & 16) and np.all(k["flags"] & 2)
+        outs.append(k)
+    assert_recs_equal(np.concatenate(outs), want, "gated shards + fixup")

@@ -41,6 +41,19 @@ def gen_stream_blocks(n_local, origin, fs, bursts_per_s, seed, device, block=1 <
     return out
 
 
+def pmc_traffic(fs, log2n, bursts):
+    """HBM bytes per k_detect launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json), if this
+    exact workload was profiled; PMC collection needs its own rocprofv3 run, it cannot happen inside bench.py."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            for e in json.load(f)["entries"]:
+                if e["fs"] == fs and e["log2n"] == log2n and e["bursts"] == bursts:
+                    return int(e["traffic_bytes"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(iq_host, sps, thr, reps=3):
     """Single-core C port of the reference path (oracle/adsb_oracle.c) on a bounded sample."""
     from oracle import c_oracle as C
@@ -202,7 +215,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                 "kernel_only_msamples_per_s": round(alg_bytes / 8 / (kern_ms * 1e-3) / 1e6, 1) if kern_ms > 0 else 0.0,
-                "traffic": None,
+                "traffic": pmc_traffic(fs, args.log2n, args.bursts) if n_gpus == 1 else None,
+                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
             },
         }
         if not args.no_cpu and n_gpus == 1:

@@ -235,7 +235,7 @@ def test_full_size_properties(native, torch_mod):
     iq = M.synth_iq_torch(n, fs, 1000, 1, torch.device("cuda:0"))
     fe = FrontEnd(fs, 0.01)
     whole = fe.process_iq_tensor(iq)
-    assert 200000 < len(whole) < 280000
+    assert 100000 < len(whole) < 140000      # 134 s of signal at ~1000 bursts/s, some lost to collisions
     d = np.diff(whole["offset"])
     assert d.min() > 63 * sps
     again = fe.process_iq_tensor(iq)
@@ -254,6 +254,6 @@ def test_full_size_properties(native, torch_mod):
         assert len(common), "no common burst near the window start"
         c0 = common[0]
         assert_recs_equal(a[a["offset"] >= c0], b[b["offset"] >= c0], "window @%d" % start)
-        assert (a["offset"] >= c0).sum() > 3000
+        assert (a["offset"] >= c0).sum() > 1000
     lists = [fe.shard_tensor(iq[p["lo"]:p["hi"]], p["lo"], p["own_lo"], p["own_hi"], n) for p in shard_plan(n, 8, sps)]
     assert fe.stitch(lists).tobytes() == whole.tobytes()

@@ -129,6 +129,22 @@ __device__ __forceinline__ float xg(const void* data, long long n, long long i) 
   return reinterpret_cast<const float*>(data)[i];
 }
 
+// Branch-free variant for gathers: the load is always issued (from a clamped, always valid index) and the
+// result is selected afterwards, so a wavefront can keep many of them in flight.  Needs n >= 1.
+template <int MODE>
+__device__ __forceinline__ float xg_nb(const void* data, long long n, long long i) {
+  const bool ok = (i >= 0) & (i < n);
+  const long long ci = ok ? i : 0;
+  float v;
+  if (MODE == 0) {
+    const float2 q = reinterpret_cast<const float2*>(data)[ci];
+    v = mag2f(q.x, q.y);
+  } else {
+    v = reinterpret_cast<const float*>(data)[ci];
+  }
+  return ok ? v : 0.0f;
+}
+
 template <int MODE>
 __device__ __forceinline__ bool above_at(const DetectArgs& a, long long i) {
   if (i >= 0) return xg<MODE>(a.data, a.n, i) >= a.thr;
@@ -175,23 +191,25 @@ __device__ void emit_record(const DetectArgs& a, long long p, unsigned xflags, R
   const bool dem1 = dem && lane < 48;
   const long long s0 = p + 8ll * sps + (long long)lane * sps;             // demod.py:75,87
   const long long s1 = s0 + 64ll * sps;
-  // every global read of this burst is issued before any of them is used
-  const float peak = xg<MODE>(d, n, p);
-  const float v0 = val0 ? xg<MODE>(d, n, wlo + lane) : 0.0f;
-  const float v1 = val1 ? xg<MODE>(d, n, wlo + lane + 64) : 0.0f;
-  const float x1 = dem ? xg<MODE>(d, n, s0) : 0.0f;
-  const float x0 = dem ? xg<MODE>(d, n, s0 + half) : 0.0f;                // demod.py:91
-  const float y1 = dem1 ? xg<MODE>(d, n, s1) : 0.0f;
-  const float y0 = dem1 ? xg<MODE>(d, n, s1 + half) : 0.0f;
+  // every global read of this burst is issued (branch-free) before any of them is used
+  const float peak = xg_nb<MODE>(d, n, p);
+  const float w0 = xg_nb<MODE>(d, n, wlo + lane);
+  const float w1 = xg_nb<MODE>(d, n, wlo + lane + 64);
+  const float x1 = xg_nb<MODE>(d, n, s0);
+  const float x0 = xg_nb<MODE>(d, n, s0 + half);                          // demod.py:91
+  const float y1 = xg_nb<MODE>(d, n, s1);
+  const float y0 = xg_nb<MODE>(d, n, s1 + half);
+  const float v0 = val0 ? w0 : 0.0f;
+  const float v1 = val1 ? w1 : 0.0f;
 
   const unsigned long long nanm = __ballot((val0 && v0 != v0) || (val1 && v1 != v1));
   const unsigned k0 = val0 ? f32_key(v0) : 0xFFFFFFFFu;      // lanes outside the window sort last
   const unsigned k1 = val1 ? f32_key(v1) : 0xFFFFFFFFu;
-  int k = (nwin - 1) >> 1;                                   // lower middle (the middle for odd n)
-  unsigned prefix = 0;
+  int k = adsb_uniform((nwin - 1) >> 1);                     // lower middle (the middle for odd n)
+  unsigned prefix = 0;                                       // k, prefix, c0 are wave-uniform: scalar registers
   for (int bit = 31; bit >= 0; --bit) {
     const unsigned want = prefix >> bit;                     // bucket members whose current bit is 0
-    const int c0 = __popcll(__ballot((k0 >> bit) == want)) + __popcll(__ballot((k1 >> bit) == want));
+    const int c0 = adsb_uniform(__popcll(__ballot((k0 >> bit) == want)) + __popcll(__ballot((k1 >> bit) == want)));
     if (k >= c0) { k -= c0; prefix |= 1u << bit; }
   }
   const unsigned A = prefix;                                 // key of the lower middle

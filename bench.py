@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-log2n", type=int, default=26, help="log2 of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--format", choices=["fc32", "sc16"], default="fc32",
+                    help="input sample format: complex64 (BASELINE workload) or int16 IQ (4 B/sample; N=1 only)")
     args = ap.parse_args()
 
     import torch
@@ -109,9 +111,14 @@ def main():
     stream_len = n_own * n_gpus
     fe = FrontEnd(fs, args.threshold, device=local_rank, timing=True)
 
+    sc16 = args.format == "sc16"
+    assert not (sc16 and n_gpus > 1)
     if n_gpus == 1:
         iq = gen_stream_blocks(n_own, 0, fs, args.bursts, args.seed, dev)
         plan = None
+        if sc16:   # quantise the same stream to int16 (full scale 4.0); the kernel converts with the same scale
+            fe.ctx.set_iq16_scale(4.0 / 32767.0)
+            iq = torch.clamp(torch.round(iq * (32767.0 / 4.0)), -32768, 32767).to(torch.int16).contiguous()
     else:
         plan = shard_plan(stream_len, n_gpus, sps, align=n_own)[rank]
         iq = gen_stream_blocks(plan["hi"] - plan["lo"], plan["lo"], fs, args.bursts, args.seed, dev)
@@ -123,7 +130,7 @@ def main():
         if n_gpus == 1:
             # submit pass i+1 before collecting pass i: the PCIe copy and host work of one pass overlap the
             # kernels of the next; every pass is collected inside the timed region (drain() below)
-            pending.append(fe.submit_iq_tensor(iq, 0))
+            pending.append(fe.submit_iq16_tensor(iq, 0) if sc16 else fe.submit_iq_tensor(iq, 0))
             if len(pending) == 2:
                 return fe.wait(pending.pop(0), fetch=False)
             return 0
@@ -198,28 +205,28 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.format == "fc32" else "i16->f32",
             "data": "synthetic",
             "config": {
-                "workload": "synthetic %g Msps complex64 IQ, %g DF17-length bursts/s, AWGN 1e-3, threshold %g; "
+                "workload": "synthetic %g Msps %s IQ, %g DF17-length bursts/s, AWGN 1e-3, threshold %g; "
                             "2^%d samples per GPU per step resident in HBM; one canonical framer+demod pass"
-                            % (fs / 1e6, args.bursts, args.threshold, args.log2n),
+                            % (fs / 1e6, "int16" if sc16 else "complex64", args.bursts, args.threshold, args.log2n),
                 "fs": fs, "samples_per_gpu_per_step": n_own, "bursts_per_step_rank0": int(n_bursts),
                 "sharding": "none" if n_gpus == 1 else "%d overlapped time shards, host stitch" % n_gpus,
                 "pipeline": "2 passes in flight (submit/wait)",
                 "detect_grid": int(st["detect_grid"]), "retries": int(st["retries"]), "longrun_calls": int(st["longrun_calls"]),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_detect<complex64>",
+                "bound": "hbm", "kernel": "k_detect<%s>" % ("int16 IQ" if sc16 else "complex64"),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                 "kernel_only_msamples_per_s": round(alg_bytes / 8 / (kern_ms * 1e-3) / 1e6, 1) if kern_ms > 0 else 0.0,
-                "traffic": pmc_traffic(fs, args.log2n, args.bursts) if n_gpus == 1 else None,
+                "traffic": pmc_traffic(fs, args.log2n, args.bursts) if (n_gpus == 1 and not sc16) else None,
                 "traffic_source": "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
             },
         }
-        if not args.no_cpu and n_gpus == 1:
+        if not args.no_cpu and n_gpus == 1 and not sc16:
             n_cpu = min(n_own, 1 << args.cpu_log2n)
             host = iq[:n_cpu].cpu().numpy().view(np.complex64).reshape(-1)
             msps, crecs = cpu_baseline(host, sps, args.threshold)

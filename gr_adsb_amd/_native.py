@@ -21,9 +21,10 @@ BURST_KEPT = 2
 EXPORTS = [
     "adsb_abi_version", "adsb_create", "adsb_destroy", "adsb_set_threshold", "adsb_set_stream", "adsb_reset",
     "adsb_process_iq", "adsb_process_mag2", "adsb_process_iq_device", "adsb_process_mag2_device", "adsb_last_result",
-    "adsb_submit_iq_device", "adsb_submit_mag2_device", "adsb_submit_shard_device", "adsb_wait",
+    "adsb_submit_iq_device", "adsb_submit_mag2_device", "adsb_submit_iq16_device", "adsb_submit_shard_device", "adsb_wait",
+    "adsb_set_iq16_scale", "adsb_process_iq16", "adsb_process_iq16_device",
     "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_get_stats",
-    "adsb_reset_stats", "adsb_last_error",
+    "adsb_reset_stats", "adsb_last_error", "adsb_host_alloc", "adsb_host_free",
 ]
 
 
@@ -70,7 +71,10 @@ def load():
     lib.adsb_set_threshold.argtypes = [vp, f32]
     lib.adsb_set_stream.argtypes = [vp, vp]
     lib.adsb_reset.argtypes = [vp]
-    for name in ("adsb_process_iq", "adsb_process_mag2", "adsb_process_iq_device", "adsb_process_mag2_device"):
+    lib.adsb_set_iq16_scale.argtypes = [vp, f32]
+    lib.adsb_submit_iq16_device.argtypes = [vp, vp, i64, i64, c.POINTER(i32)]
+    for name in ("adsb_process_iq", "adsb_process_mag2", "adsb_process_iq_device", "adsb_process_mag2_device",
+                 "adsb_process_iq16", "adsb_process_iq16_device"):
         getattr(lib, name).argtypes = [vp, vp, i64, i64, vp, i32, c.POINTER(i32)]
     lib.adsb_last_result.argtypes = [vp, c.POINTER(vp), c.POINTER(i32)]
     lib.adsb_submit_iq_device.argtypes = [vp, vp, i64, i64, c.POINTER(i32)]
@@ -86,6 +90,8 @@ def load():
     lib.adsb_snr_db.restype = f32
     lib.adsb_get_stats.argtypes = [vp, c.POINTER(Stats)]
     lib.adsb_reset_stats.argtypes = [vp]
+    lib.adsb_host_alloc.argtypes = [c.POINTER(vp), c.c_size_t]
+    lib.adsb_host_free.argtypes = [vp]
     lib.adsb_last_error.argtypes = [vp]
     lib.adsb_last_error.restype = c.c_char_p
     _lib = lib
@@ -154,6 +160,25 @@ class Context:
         x = np.ascontiguousarray(x, dtype=np.float32)
         return self._run(self.lib.adsb_process_mag2, x.ctypes.data, len(x), abs_offset)
 
+    def set_iq16_scale(self, scale):
+        self._chk(self.lib.adsb_set_iq16_scale(self._h, float(np.float32(scale))))
+
+    def process_iq16(self, iq16, abs_offset=0):
+        """iq16: int16 array of interleaved I,Q (2n shorts)."""
+        iq16 = np.ascontiguousarray(iq16, dtype=np.int16)
+        return self._run(self.lib.adsb_process_iq16, iq16.ctypes.data, len(iq16) // 2, abs_offset)
+
+    def process_iq16_device(self, dev_ptr, n, abs_offset=0, fetch=True):
+        n_out = ctypes.c_int32(0)
+        self._chk(self.lib.adsb_process_iq16_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(n), int(abs_offset), None, 0,
+                                                    ctypes.byref(n_out)))
+        return self.last_result() if fetch else n_out.value
+
+    def submit_iq16_device(self, dev_ptr, n, abs_offset=0):
+        t = ctypes.c_int32(-1)
+        self._chk(self.lib.adsb_submit_iq16_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(n), int(abs_offset), ctypes.byref(t)))
+        return t.value
+
     def process_iq_device(self, dev_ptr, n, abs_offset=0, fetch=True):
         n_out = ctypes.c_int32(0)
         self._chk(self.lib.adsb_process_iq_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(n), int(abs_offset), None, 0,
@@ -220,6 +245,29 @@ class Context:
 
     def reset_stats(self):
         self._chk(self.lib.adsb_reset_stats(self._h))
+
+
+class PinnedArray:
+    """NumPy view of page-locked host memory from adsb_host_alloc (freed when this object dies)."""
+
+    def __init__(self, n, dtype):
+        self.lib = load()
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(n) * self.dtype.itemsize
+        self._p = ctypes.c_void_p()
+        rc = self.lib.adsb_host_alloc(ctypes.byref(self._p), max(1, self.nbytes))
+        if rc != 0:
+            raise AdsbError(rc, "adsb_host_alloc")
+        buf = (ctypes.c_char * max(1, self.nbytes)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(n))
+
+    def __del__(self):
+        try:
+            if self._p.value:
+                self.lib.adsb_host_free(self._p)
+                self._p = ctypes.c_void_p()
+        except Exception:
+            pass
 
 
 def stitch(cands, sps):

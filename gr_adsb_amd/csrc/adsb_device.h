@@ -90,7 +90,7 @@ struct Summary {
 };
 
 struct DetectArgs {
-  const void* data;      // float2[n] (MODE 0, complex64 IQ) or float[n] (MODE 1, |IQ|^2)
+  const void* data;      // MODE 0: float2[n] complex64 IQ; MODE 1: float[n] |IQ|^2; MODE 2: short2[n] int16 IQ
   long long n;           // samples present; x(i) = 0 for i < 0 or i >= n
   long long in0_base;    // local index of the framer's in0[0] (-(8*sps-1) on a fresh stream)
   long long scan_lo;     // rises (and falls) are owned / counted in [scan_lo, scan_hi)
@@ -101,6 +101,7 @@ struct DetectArgs {
   long long chunk;       // samples per workgroup (multiple of kTile)
   float thr;
   float prev_in0;        // value compared for the sample before in0[0] (framer.py:84)
+  float scale;           // MODE 2: float32 multiplier applied to every int16 component
   int sps;
   int end_is_call_end;   // 1: pulse still high at fall_hi is discarded (framer.py:102-108); 0: halo error
   int rec_cap;           // centres per workgroup
@@ -119,35 +120,42 @@ __device__ __forceinline__ float mag2f(float re, float im) {
   return __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
 }
 
+// int16 IQ: component -> float32 exactly, times `scale` (one rounded multiply), then |.|^2 as above
+__device__ __forceinline__ float mag2_iq16(unsigned iq, float scale) {
+  const float re = __fmul_rn((float)(short)(iq & 0xFFFFu), scale);
+  const float im = __fmul_rn((float)(short)(iq >> 16), scale);
+  return mag2f(re, im);
+}
+
 template <int MODE>
-__device__ __forceinline__ float xg(const void* data, long long n, long long i) {
-  if (i < 0 || i >= n) return 0.0f;
+__device__ __forceinline__ float load_sample(const void* data, long long i, float scale) {
   if (MODE == 0) {
-    float2 q = reinterpret_cast<const float2*>(data)[i];
+    const float2 q = reinterpret_cast<const float2*>(data)[i];
     return mag2f(q.x, q.y);
   }
+  if (MODE == 2) return mag2_iq16(reinterpret_cast<const unsigned*>(data)[i], scale);
   return reinterpret_cast<const float*>(data)[i];
+}
+
+template <int MODE>
+__device__ __forceinline__ float xg(const void* data, long long n, long long i, float scale) {
+  if (i < 0 || i >= n) return 0.0f;
+  return load_sample<MODE>(data, i, scale);
 }
 
 // Branch-free variant for gathers: the load is always issued (from a clamped, always valid index) and the
 // result is selected afterwards, so a wavefront can keep many of them in flight.  Needs n >= 1.
 template <int MODE>
-__device__ __forceinline__ float xg_nb(const void* data, long long n, long long i) {
+__device__ __forceinline__ float xg_nb(const void* data, long long n, long long i, float scale) {
   const bool ok = (i >= 0) & (i < n);
   const long long ci = ok ? i : 0;
-  float v;
-  if (MODE == 0) {
-    const float2 q = reinterpret_cast<const float2*>(data)[ci];
-    v = mag2f(q.x, q.y);
-  } else {
-    v = reinterpret_cast<const float*>(data)[ci];
-  }
+  const float v = load_sample<MODE>(data, ci, scale);
   return ok ? v : 0.0f;
 }
 
 template <int MODE>
 __device__ __forceinline__ bool above_at(const DetectArgs& a, long long i) {
-  if (i >= 0) return xg<MODE>(a.data, a.n, i) >= a.thr;
+  if (i >= 0) return xg<MODE>(a.data, a.n, i, a.scale) >= a.thr;
   if (i == a.in0_base - 1) return a.prev_in0 >= a.thr;
   return 0.0f >= a.thr;
 }
@@ -192,13 +200,13 @@ __device__ void emit_record(const DetectArgs& a, long long p, unsigned xflags, R
   const long long s0 = p + 8ll * sps + (long long)lane * sps;             // demod.py:75,87
   const long long s1 = s0 + 64ll * sps;
   // every global read of this burst is issued (branch-free) before any of them is used
-  const float peak = xg_nb<MODE>(d, n, p);
-  const float w0 = xg_nb<MODE>(d, n, wlo + lane);
-  const float w1 = xg_nb<MODE>(d, n, wlo + lane + 64);
-  const float x1 = xg_nb<MODE>(d, n, s0);
-  const float x0 = xg_nb<MODE>(d, n, s0 + half);                          // demod.py:91
-  const float y1 = xg_nb<MODE>(d, n, s1);
-  const float y0 = xg_nb<MODE>(d, n, s1 + half);
+  const float peak = xg_nb<MODE>(d, n, p, a.scale);
+  const float w0 = xg_nb<MODE>(d, n, wlo + lane, a.scale);
+  const float w1 = xg_nb<MODE>(d, n, wlo + lane + 64, a.scale);
+  const float x1 = xg_nb<MODE>(d, n, s0, a.scale);
+  const float x0 = xg_nb<MODE>(d, n, s0 + half, a.scale);                          // demod.py:91
+  const float y1 = xg_nb<MODE>(d, n, s1, a.scale);
+  const float y0 = xg_nb<MODE>(d, n, s1 + half, a.scale);
   const float v0 = val0 ? w0 : 0.0f;
   const float v1 = val1 ? w1 : 0.0f;
 
@@ -253,7 +261,7 @@ __device__ void emit_record(const DetectArgs& a, long long p, unsigned xflags, R
 // masks cost no LDS re-read.  The fast path (whole span inside the buffer) has no per-load branches.
 template <int MODE, int COUNT>
 struct Span {
-  static constexpr int PER = (MODE == 0) ? 2 : 4;             // samples per float4
+  static constexpr int PER = (MODE == 0) ? 2 : 4;             // samples per 16-byte load (complex64: 2; float / int16 IQ: 4)
   static constexpr int SHARE = COUNT / kWaves;                // samples per wavefront
   static constexpr int GROUP = 64 * PER;                      // samples per wave-wide load
   static constexpr int ITER = (SHARE + GROUP - 1) / GROUP;    // (a partial last group only for the head span)
@@ -269,7 +277,8 @@ __device__ __forceinline__ bool span_issue(Span<MODE, COUNT>& sp, const DetectAr
   if (src + COUNT > a.n) return false;
   // scalar base + 32-bit lane offset: one address VGPR for all loads of the span
   const long long wsrc = src + (long long)wave * S::SHARE;
-  const char* ub = reinterpret_cast<const char*>(a.data) + wsrc * (16 / S::PER);
+  constexpr int BPS = (MODE == 0) ? 8 : 4;                    // bytes per sample
+  const char* ub = reinterpret_cast<const char*>(a.data) + wsrc * BPS;
   const unsigned lo = (unsigned)lane * 16u;
 #pragma unroll
   for (int k = 0; k < S::ITER; ++k) {
@@ -285,7 +294,7 @@ template <int MODE, int COUNT>
 __device__ __forceinline__ void span_fill_ragged(float* sx, unsigned long long* smask, int dst,
                                                            const DetectArgs& a, long long src) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < COUNT; i += kThreads) sx[dst + i] = xg<MODE>(a.data, a.n, src + i);
+  for (int i = tid; i < COUNT; i += kThreads) sx[dst + i] = xg<MODE>(a.data, a.n, src + i, a.scale);
   __syncthreads();
   for (int w = wave; w < COUNT / 64; w += kWaves) {
     const unsigned long long m = __ballot(sx[dst + 64 * w + lane] >= a.thr);
@@ -298,7 +307,7 @@ __device__ __forceinline__ void span_fill_ragged(float* sx, unsigned long long* 
 // its low lanes for data and writes one mask word.
 template <int MODE, int COUNT>
 __device__ __forceinline__ void span_commit(const Span<MODE, COUNT>& sp, float* sx, unsigned long long* smask,
-                                            int dst, float thr, int wave, int lane) {
+                                            int dst, float thr, float scale, int wave, int lane) {
   using S = Span<MODE, COUNT>;
   const int wdst = dst + wave * S::SHARE;
   const bool act = (S::LANES == 64) || lane < S::LANES;
@@ -322,10 +331,17 @@ __device__ __forceinline__ void span_commit(const Span<MODE, COUNT>& sp, float* 
         }
       }
     } else {
-      if (act) *reinterpret_cast<float4*>(&sx[g + 4 * lane]) = sp.q[k];
+      float4 m = sp.q[k];
+      if (MODE == 2) {                                        // 8 int16 -> 4 |IQ|^2
+        m.x = mag2_iq16(__builtin_bit_cast(unsigned, sp.q[k].x), scale);
+        m.y = mag2_iq16(__builtin_bit_cast(unsigned, sp.q[k].y), scale);
+        m.z = mag2_iq16(__builtin_bit_cast(unsigned, sp.q[k].z), scale);
+        m.w = mag2_iq16(__builtin_bit_cast(unsigned, sp.q[k].w), scale);
+      }
+      if (act) *reinterpret_cast<float4*>(&sx[g + 4 * lane]) = m;
       if (kAblate < 3) {
-        const unsigned long long A = __ballot(act && sp.q[k].x >= thr), B = __ballot(act && sp.q[k].y >= thr);
-        const unsigned long long C = __ballot(act && sp.q[k].z >= thr), D = __ballot(act && sp.q[k].w >= thr);
+        const unsigned long long A = __ballot(act && m.x >= thr), B = __ballot(act && m.y >= thr);
+        const unsigned long long C = __ballot(act && m.z >= thr), D = __ballot(act && m.w >= thr);
         const int c = lane & 3;
         const unsigned long long sel = (c == 0) ? A : (c == 1) ? B : (c == 2) ? C : D;
         const int sh = lane >> 2;
@@ -385,7 +401,7 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
     Span<MODE, kFwd> head;
     const bool head_ok = span_issue<MODE, kFwd>(head, a, c0, wave, lane);
     body_ok = span_issue<MODE, kTile>(body, a, c0 + kFwd, wave, lane);
-    if (head_ok) span_commit<MODE, kFwd>(head, s_x, s_mask, 0, a.thr, wave, lane);
+    if (head_ok) span_commit<MODE, kFwd>(head, s_x, s_mask, 0, a.thr, a.scale, wave, lane);
     else span_fill_ragged<MODE, kFwd>(s_x, s_mask, 0, a, c0);
   }
 
@@ -393,7 +409,7 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
     // -- A: window [t0, t0+kWin).  s_x[0..kFwd) and mask words 0..3 already hold the head; commit the body
     //       (floats + mask words 4..67), then start fetching the next body so it is in flight below
     if (!body_ok) span_fill_ragged<MODE, kTile>(s_x, s_mask, kFwd, a, t0 + kFwd);
-    else if (kAblate < 4) span_commit<MODE, kTile>(body, s_x, s_mask, kFwd, a.thr, wave, lane);
+    else if (kAblate < 4) span_commit<MODE, kTile>(body, s_x, s_mask, kFwd, a.thr, a.scale, wave, lane);
     else { float acc = 0.0f; for (int k = 0; k < Span<MODE, kTile>::ITER; ++k) acc += body.q[k].x + body.q[k].w; if (acc == 123.456f) s_x[tid] = acc; }
     if (t0 + kTile < c1) body_ok = span_issue<MODE, kTile>(body, a, t0 + kTile + kFwd, wave, lane);
     __syncthreads();
@@ -457,7 +473,7 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
 #pragma unroll 1
               for (int k = 0; k < 16; ++k) {
                 const int idx = p + k * half;
-                const float v = (idx < kWin) ? s_x[idx] : xg<MODE>(a.data, a.n, t0 + idx);
+                const float v = (idx < kWin) ? s_x[idx] : xg<MODE>(a.data, a.n, t0 + idx, a.scale);
                 chips |= (v > hp ? 1u : 0u) << k;
               }
             }
@@ -591,8 +607,8 @@ __global__ void __launch_bounds__(kThreads) k_longrun(DetectArgs a) {
       if (f < limit) {
         const long long p = (le.rise + f) >> 1;            // floor, also for negative indices
         if (lane == 0) atomicMax(a.long_lastp, (unsigned long long)(p + (1ll << 62)));
-        const float hp = __fmul_rn(xg<MODE>(a.data, a.n, p), 0.5f);
-        const float v = (lane < 16) ? xg<MODE>(a.data, a.n, p + (long long)lane * (a.sps >> 1)) : 0.0f;
+        const float hp = __fmul_rn(xg<MODE>(a.data, a.n, p, a.scale), 0.5f);
+        const float v = (lane < 16) ? xg<MODE>(a.data, a.n, p + (long long)lane * (a.sps >> 1), a.scale) : 0.0f;
         const unsigned long long cm = __ballot(lane < 16 && v > hp);
         if (lane == 0) *out = ((unsigned)cm == kTemplate) ? cand_make(p, 0u) : cand_make(p, kNoMatch);
       } else if (lane == 0) {
@@ -810,11 +826,11 @@ __global__ void __launch_bounds__(kThreads) k_slice(const void* data, long long 
     float q0 = 0.0f, q1 = 0.0f;
     if (dem) {
       const long long s0 = p + 8ll * sps + (long long)lane * sps;
-      const float x1 = xg<MODE>(data, n, s0), x0 = xg<MODE>(data, n, s0 + half);
+      const float x1 = xg<MODE>(data, n, s0, 1.0f), x0 = xg<MODE>(data, n, s0 + half, 1.0f);
       b0 = x1 > x0; q0 = __fdiv_rn(x1, x0);
       if (lane < 48) {
         const long long s1 = s0 + 64ll * sps;
-        const float y1 = xg<MODE>(data, n, s1), y0 = xg<MODE>(data, n, s1 + half);
+        const float y1 = xg<MODE>(data, n, s1, 1.0f), y0 = xg<MODE>(data, n, s1 + half, 1.0f);
         b1 = y1 > y0; q1 = __fdiv_rn(y1, y0);
       }
     }

@@ -74,7 +74,8 @@ struct adsb_ctx {
   hipStream_t copy_stream = nullptr;  // device -> pinned host result copies
   bool own_stream = false;
   int n_cu = 256;
-  int bpc[2] = {4, 4};  // resident k_detect workgroups per CU (occupancy query), per input mode
+  int bpc[3] = {4, 4, 4};  // resident k_detect workgroups per CU (occupancy query), per input mode
+  float scale16 = 1.0f / 32768.0f;  // int16 IQ component -> float32 multiplier (adsb_set_iq16_scale)
   FramerState st;       // framer.py:54,57
   Slot slot[2];
   int next_slot = 0;
@@ -162,7 +163,8 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, c->stream, (const unsigned long long*)sorted, &misc->sum,
                      (const int*)s.d_seg.p, fmask, fwant, pl.head_n, kept, (int)s.tot);
   if (pl.mode == 0) launch_burst<0>(c, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
-  else launch_burst<1>(c, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
+  else if (pl.mode == 1) launch_burst<1>(c, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
+  else launch_burst<2>(c, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
   HIPCHK(c, hipMemcpyAsync(s.h_sum, &misc->sum, sizeof(Summary), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipEventRecord(s.done, c->stream));
   return 0;
@@ -203,7 +205,7 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   DetectArgs& a = s.args;
   a.data = pl.d_data; a.n = pl.n; a.in0_base = pl.in0_base; a.scan_lo = pl.scan_lo; a.scan_hi = pl.scan_hi;
   a.fall_hi = pl.fall_hi; a.dem_hi = pl.dem_hi; a.origin = pl.origin; a.chunk = chunk; a.thr = c->thr;
-  a.prev_in0 = pl.prev_in0; a.sps = c->sps; a.end_is_call_end = pl.end_is_call_end; a.rec_cap = s.rec_cap;
+  a.prev_in0 = pl.prev_in0; a.scale = c->scale16; a.sps = c->sps; a.end_is_call_end = pl.end_is_call_end; a.rec_cap = s.rec_cap;
   a.long_cap = (int)long_cap; a.cands = (unsigned long long*)s.d_cands.p; a.blk_count = (int*)s.d_blk_count.p;
   a.blk_lastp = (long long*)s.d_blk_lastp.p; a.blk_flags = (unsigned*)s.d_blk_flags.p;
   a.longlist = (LongRise*)s.d_long.p; a.long_count = &misc->long_count; a.long_lastp = &misc->long_lastp;
@@ -211,9 +213,9 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   HIPCHK(c, hipMemsetAsync(misc, 0, 16, c->stream));
   const bool timing = (c->flags & ADSB_FLAG_TIMING) != 0;
   if (timing) HIPCHK(c, hipEventRecord(s.ev0, c->stream));
-  if (pl.mode == 0) launch_detect<0>(c, a, grid); else launch_detect<1>(c, a, grid);
+  if (pl.mode == 0) launch_detect<0>(c, a, grid); else if (pl.mode == 1) launch_detect<1>(c, a, grid); else launch_detect<2>(c, a, grid);
   if (timing) HIPCHK(c, hipEventRecord(s.ev1, c->stream));
-  if (pl.mode == 0) launch_longrun<0>(c, a); else launch_longrun<1>(c, a);   // no-op unless k_detect listed long pulses
+  if (pl.mode == 0) launch_longrun<0>(c, a); else if (pl.mode == 1) launch_longrun<1>(c, a); else launch_longrun<2>(c, a);   // no-op unless k_detect listed long pulses
   c->stats.detect_grid = (uint64_t)grid; c->stats.blocks_per_cu = (uint64_t)c->bpc[pl.mode];
   c->stats.calls++;
   s.busy = true;
@@ -296,12 +298,24 @@ int canonical(adsb_ctx* c, int mode, const void* d_data, int64_t n, int64_t abs_
   return deliver(c, nres, out, cap, n_out);
 }
 
+bool is_pinned_host(const void* p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // pageable
+  return at.type == hipMemoryTypeHost;
+}
+
+// Host buffer -> device staging buffer.  Pinned sources (adsb_host_alloc, hipHostMalloc, torch pin_memory)
+// go straight over PCIe; pageable ones are first copied into the context's pinned staging buffer.
 int upload(adsb_ctx* c, const void* host, size_t bytes, void** d_out) {
   int rc;
   if ((rc = ensure(c, c->d_in, bytes + 64))) return rc;
-  if ((rc = ensure_pinned(c, c->h_stage, c->h_stage_cap, bytes))) return rc;
-  memcpy(c->h_stage, host, bytes);
-  HIPCHK(c, hipMemcpyAsync(c->d_in.p, c->h_stage, bytes, hipMemcpyHostToDevice, c->stream));
+  const void* src = host;
+  if (!is_pinned_host(host)) {
+    if ((rc = ensure_pinned(c, c->h_stage, c->h_stage_cap, bytes))) return rc;
+    memcpy(c->h_stage, host, bytes);
+    src = c->h_stage;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_in.p, src, bytes, hipMemcpyHostToDevice, c->stream));
   *d_out = c->d_in.p;
   return 0;
 }
@@ -340,6 +354,7 @@ int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_detect<0>, kThreads, 0) == hipSuccess && nb > 0) c->bpc[0] = nb;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_detect<1>, kThreads, 0) == hipSuccess && nb > 0) c->bpc[1] = nb;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_detect<2>, kThreads, 0) == hipSuccess && nb > 0) c->bpc[2] = nb;
   }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return -EIO; }
   c->own_stream = true;
@@ -402,6 +417,28 @@ int adsb_process_iq_device(adsb_ctx* c, const void* d_iq, int64_t n, int64_t abs
   return canonical(c, 0, d_iq, n, abs_offset, out, cap, n_out);
 }
 
+int adsb_set_iq16_scale(adsb_ctx* c, float scale) {
+  if (!c) return -EINVAL;
+  c->scale16 = scale;
+  return 0;
+}
+
+int adsb_process_iq16_device(adsb_ctx* c, const void* d_iq16, int64_t n, int64_t abs_offset, adsb_burst* out,
+                             int32_t cap, int32_t* n_out) {
+  return canonical(c, 2, d_iq16, n, abs_offset, out, cap, n_out);
+}
+
+int adsb_process_iq16(adsb_ctx* c, const int16_t* iq16_host, int64_t n, int64_t abs_offset, adsb_burst* out,
+                      int32_t cap, int32_t* n_out) {
+  if (!c || n < 0 || (n > 0 && !iq16_host)) return -EINVAL;
+  if (n == 0) { if (n_out) *n_out = 0; c->slot[c->last_slot].nres = 0; return 0; }
+  HIPCHK(c, hipSetDevice(c->device));
+  void* d = nullptr;
+  int rc = upload(c, iq16_host, (size_t)n * 4, &d);
+  if (rc) return rc;
+  return canonical(c, 2, d, n, abs_offset, out, cap, n_out);
+}
+
 int adsb_process_mag2_device(adsb_ctx* c, const void* d_mag2, int64_t n, int64_t abs_offset, adsb_burst* out,
                              int32_t cap, int32_t* n_out) {
   return canonical(c, 1, d_mag2, n, abs_offset, out, cap, n_out);
@@ -447,6 +484,10 @@ static int submit_canonical(adsb_ctx* c, int mode, const void* d_data, int64_t n
 
 int adsb_submit_iq_device(adsb_ctx* c, const void* d_iq, int64_t n, int64_t abs_offset, int32_t* ticket) {
   return submit_canonical(c, 0, d_iq, n, abs_offset, ticket);
+}
+
+int adsb_submit_iq16_device(adsb_ctx* c, const void* d_iq16, int64_t n, int64_t abs_offset, int32_t* ticket) {
+  return submit_canonical(c, 2, d_iq16, n, abs_offset, ticket);
 }
 
 int adsb_submit_mag2_device(adsb_ctx* c, const void* d_mag2, int64_t n, int64_t abs_offset, int32_t* ticket) {
@@ -550,7 +591,7 @@ static int shard_post(adsb_ctx* c, Slot& s, const Summary& sum, int32_t nres) {
 
 static int shard_plan_checked(adsb_ctx* c, int fmt, const void* d_data, int64_t n, int64_t origin, int64_t own_lo,
                               int64_t own_hi, int64_t stream_len, int32_t head_cands, Plan* pl) {
-  if (!c || n < 0 || (fmt != 0 && fmt != 1) || head_cands < 0) return -EINVAL;
+  if (!c || n < 0 || fmt < 0 || fmt > 2 || head_cands < 0) return -EINVAL;
   if (((uintptr_t)d_data & 15u) != 0) return fail(c, -EINVAL, "device pointer must be 16-byte aligned");
   *pl = plan_shard(fmt, d_data, n, origin, own_lo, own_hi, stream_len, c->sps, head_cands);
   if (origin > 0 && pl->scan_lo < 1) return fail(c, -EINVAL, "shard needs at least one sample of back halo");
@@ -634,6 +675,17 @@ int adsb_stitch(adsb_burst* cands, int32_t n, int sps, int32_t* n_kept) {
   }
   if (n_kept) *n_kept = w;
   return 0;
+}
+
+int adsb_host_alloc(void** p, size_t bytes) {
+  if (!p || bytes == 0) return -EINVAL;
+  *p = nullptr;
+  return hipHostMalloc(p, bytes, hipHostMallocDefault) == hipSuccess ? 0 : -ENOMEM;
+}
+
+int adsb_host_free(void* p) {
+  if (!p) return 0;
+  return hipHostFree(p) == hipSuccess ? 0 : -EINVAL;
 }
 
 int adsb_get_stats(adsb_ctx* c, adsb_stats* out) {

@@ -48,6 +48,12 @@ class FrontEnd:
     def process_mag2(self, x, abs_offset=0):
         return self.ctx.process_mag2(x, abs_offset)
 
+    def process_iq16(self, iq16, abs_offset=0, scale=None):
+        """iq16: interleaved int16 I,Q; scale: float32 multiplier per component (default 1/32768)."""
+        if scale is not None:
+            self.ctx.set_iq16_scale(scale)
+        return self.ctx.process_iq16(iq16, abs_offset)
+
     # -- torch tensors already in HBM ---------------------------------------------------------------
     def process_iq_tensor(self, t, abs_offset=0, fetch=True):
         """t: float32 [n,2] (or complex64 [n]) CUDA tensor, contiguous."""
@@ -58,6 +64,11 @@ class FrontEnd:
     def process_mag2_tensor(self, t, abs_offset=0, fetch=True):
         assert t.is_cuda and t.is_contiguous()
         return self.ctx.process_mag2_device(t.data_ptr(), t.shape[0], abs_offset, fetch=fetch)
+
+    def submit_iq16_tensor(self, t, abs_offset=0):
+        """t: int16 [n,2] CUDA tensor (interleaved I,Q)."""
+        assert t.is_cuda and t.is_contiguous()
+        return self.ctx.submit_iq16_device(t.data_ptr(), t.shape[0], abs_offset)
 
     def submit_iq_tensor(self, t, abs_offset=0):
         """Queue a canonical pass over t (two may be in flight); returns a ticket for wait()."""

@@ -24,6 +24,7 @@
 #ifndef ADSB_HIP_H
 #define ADSB_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -56,7 +57,7 @@ typedef struct adsb_stats {
   uint64_t detect_launches;  /* k_detect launches timed */
   double detect_ms;          /* sum of their HIP-event durations */
   uint64_t detect_samples;   /* samples those launches covered */
-  uint64_t detect_bytes;     /* algorithmic bytes: 8 B (complex64) or 4 B (float |IQ|^2) per sample */
+  uint64_t detect_bytes;     /* algorithmic bytes: 8 B (complex64) or 4 B (float |IQ|^2, int16 IQ) per sample */
   uint64_t calls;
   uint64_t retries;          /* record-capacity regrowths */
   uint64_t longrun_calls;    /* calls that needed the long-pulse kernel */
@@ -85,11 +86,25 @@ int adsb_process_iq(adsb_ctx* ctx, const float* iq_host, int64_t n, int64_t abs_
                     adsb_burst* out, int32_t cap, int32_t* n_out);
 int adsb_process_mag2(adsb_ctx* ctx, const float* mag2_host, int64_t n, int64_t abs_offset,
                       adsb_burst* out, int32_t cap, int32_t* n_out);
+/* Page-locked host memory for IQ buffers handed to adsb_process_iq / adsb_process_mag2 / adsb_framer_work:
+ * buffers allocated here (or any other pinned host memory) are DMA'd straight to the device; pageable
+ * buffers are first copied into the context's own pinned staging buffer (about 3x slower end to end). */
+int adsb_host_alloc(void** p, size_t bytes);
+int adsb_host_free(void* p);
+
 /* Same, input already in HBM (16-byte aligned device pointer).  out may be NULL: the result stays in
  * the context's pinned buffer, see adsb_last_result. */
 int adsb_process_iq_device(adsb_ctx* ctx, const void* d_iq, int64_t n, int64_t abs_offset,
                            adsb_burst* out, int32_t cap, int32_t* n_out);
 int adsb_process_mag2_device(adsb_ctx* ctx, const void* d_mag2, int64_t n, int64_t abs_offset,
+                             adsb_burst* out, int32_t cap, int32_t* n_out);
+/* int16 IQ (interleaved I,Q shorts, 4 B/sample: the SDR's native wire format).  Each
+ * component becomes float32 exactly and is multiplied by `scale` (float32, one rounded multiply; default
+ * 1/32768) before |IQ|^2; everything downstream is identical to the complex64 path. */
+int adsb_set_iq16_scale(adsb_ctx* ctx, float scale);
+int adsb_process_iq16(adsb_ctx* ctx, const int16_t* iq16_host, int64_t n, int64_t abs_offset,
+                      adsb_burst* out, int32_t cap, int32_t* n_out);
+int adsb_process_iq16_device(adsb_ctx* ctx, const void* d_iq16, int64_t n, int64_t abs_offset,
                              adsb_burst* out, int32_t cap, int32_t* n_out);
 int adsb_last_result(adsb_ctx* ctx, const adsb_burst** bursts, int32_t* n);
 
@@ -101,6 +116,7 @@ int adsb_last_result(adsb_ctx* ctx, const adsb_burst** bursts, int32_t* n);
  * in flight (-EBUSY otherwise); results must be collected in submission order. */
 int adsb_submit_iq_device(adsb_ctx* ctx, const void* d_iq, int64_t n, int64_t abs_offset, int32_t* ticket);
 int adsb_submit_mag2_device(adsb_ctx* ctx, const void* d_mag2, int64_t n, int64_t abs_offset, int32_t* ticket);
+int adsb_submit_iq16_device(adsb_ctx* ctx, const void* d_iq16, int64_t n, int64_t abs_offset, int32_t* ticket);
 int adsb_submit_shard_device(adsb_ctx* ctx, int fmt, const void* d_data, int64_t n, int64_t origin, int64_t own_lo,
                              int64_t own_hi, int64_t stream_len, int32_t head_cands, int32_t* ticket);
 int adsb_wait(adsb_ctx* ctx, int32_t ticket, adsb_burst* out, int32_t cap, int32_t* n_out);
@@ -123,7 +139,7 @@ int adsb_demod_work(adsb_ctx* ctx, const float* in0, int64_t n, int64_t nitems_r
 
 /* Overlapped time shards (multi-GPU): the device buffer holds stream samples [origin, origin+n) of
  * which this shard owns the pulse rises in [own_lo, own_hi) (stream offsets).  stream_len = length of
- * the whole stream (for the end-of-stream rules); fmt 0 = complex64, 1 = float |IQ|^2.
+ * the whole stream (for the end-of-stream rules); fmt 0 = complex64, 1 = float |IQ|^2, 2 = int16 IQ.
  *   head_cands == 0: returns EVERY matched preamble centre of the owned range, not gated (KEPT never
  *     set); adsb_stitch applies the gate over the concatenation of all shards.
  *   head_cands  > 0: the gate runs on the device as if the shard started a fresh stream (KEPT set), and

@@ -39,6 +39,16 @@ def mag2(iq):
     return re * re + im * im
 
 
+def mag2_iq16(iq16, scale):
+    """int16 interleaved IQ -> |IQ|^2 the way the HIP path's int16 input format defines it (no reference
+    counterpart): component -> float32 exactly, one rounded multiply by float32(scale),
+    then mag2."""
+    v = np.asarray(iq16, dtype=np.int16).astype(np.float32) * np.float32(scale)
+    re = np.ascontiguousarray(v[0::2])
+    im = np.ascontiguousarray(v[1::2])
+    return re * re + im * im
+
+
 def snr_db(peak, med):
     """framer.py:157/159: 10.0*np.log10(in0[p]/median) + 1.6 evaluated in float32 (NumPy 2 promotion)."""
     with np.errstate(all="ignore"):

@@ -22,7 +22,7 @@ struct SimOut {
 // mode 0: data = complex64 (2n floats); mode 1: data = float |IQ|^2.  Returns 0 or -1 (overflow of out).
 int sim_run(int mode, const float* data, long long n, long long in0_base, long long scan_lo, long long scan_hi,
             long long fall_hi, long long dem_hi, long long origin, float thr, float prev_in0, int sps,
-            int end_is_call_end, long long prev_eob_stream, int gate, int head_n, int grid_max, int rec_cap_in,
+            int end_is_call_end, long long prev_eob_stream, int gate, int head_n, int grid_max, int rec_cap_in, float scale,
             unsigned long long* out_recs /* 4 words each */, int out_cap, SimOut* so) {
   const long long span = scan_hi > 0 ? scan_hi : 0;
   long long ntiles = (span + kTile - 1) / kTile;
@@ -35,7 +35,7 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   const long long tot = (long long)grid * rec_cap;
 
   // data must be 16-byte aligned like a device allocation
-  const size_t nfl = (size_t)n * (mode == 0 ? 2 : 1);
+  const size_t nfl = (size_t)n * (mode == 0 ? 2 : 1);   // 4-byte units: complex64 = 2, float / int16 IQ = 1
   float* dbuf = (float*)aligned_alloc(64, ((nfl * 4 + 63) / 64 + 1) * 64);
   memcpy(dbuf, data, nfl * 4);
 
@@ -51,17 +51,19 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
 
   DetectArgs a;
   a.data = dbuf; a.n = n; a.in0_base = in0_base; a.scan_lo = scan_lo; a.scan_hi = scan_hi; a.fall_hi = fall_hi;
-  a.dem_hi = dem_hi; a.origin = origin; a.chunk = chunk; a.thr = thr; a.prev_in0 = prev_in0; a.sps = sps;
+  a.dem_hi = dem_hi; a.origin = origin; a.chunk = chunk; a.thr = thr; a.prev_in0 = prev_in0; a.scale = scale; a.sps = sps;
   a.end_is_call_end = end_is_call_end; a.rec_cap = rec_cap; a.long_cap = (int)(ntiles + 1);
   a.cands = cands.data(); a.blk_count = blk_count.data(); a.blk_lastp = blk_lastp.data();
   a.blk_flags = blk_flags.data(); a.longlist = longlist.data(); a.long_count = &long_count;
   a.long_lastp = &long_lastp;
 
   if (mode == 0) hipsim::launch(k_detect<0>, grid, kThreads, a);
-  else hipsim::launch(k_detect<1>, grid, kThreads, a);
+  else if (mode == 1) hipsim::launch(k_detect<1>, grid, kThreads, a);
+  else hipsim::launch(k_detect<2>, grid, kThreads, a);
 
   if (mode == 0) hipsim::launch(k_longrun<0>, 3, kThreads, a);
-  else hipsim::launch(k_longrun<1>, 3, kThreads, a);
+  else if (mode == 1) hipsim::launch(k_longrun<1>, 3, kThreads, a);
+  else hipsim::launch(k_longrun<2>, 3, kThreads, a);
   {
     hipsim::launch(k_scan, 1, kThreads, (const int*)blk_count.data(), (const long long*)blk_lastp.data(),
                    (const unsigned*)blk_flags.data(), grid, rec_cap, (const int*)&long_count,
@@ -81,7 +83,9 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
                    fmask, fwant, head_n, kept.data(), (int)tot);
     if (mode == 0) hipsim::launch(k_burst<0>, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum,
                                   outv.data(), (int)tot);
-    else hipsim::launch(k_burst<1>, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum,
+    else if (mode == 1) hipsim::launch(k_burst<1>, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum,
+                                       outv.data(), (int)tot);
+    else hipsim::launch(k_burst<2>, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum,
                         outv.data(), (int)tot);
   }
   so->n_rec = sum.n_rec; so->n_kept = sum.n_kept; so->overflow = sum.overflow; so->long_count = sum.long_count;
@@ -96,10 +100,10 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
 
 // --- the library's three call shapes, through the same adsb_plan.h the library uses ------------------
 int sim_canonical(int mode, const float* data, long long n, long long abs_offset, float thr, int sps, int grid_max,
-                  int rec_cap, unsigned long long* out, int out_cap, SimOut* so) {
+                  int rec_cap, float scale, unsigned long long* out, int out_cap, SimOut* so) {
   Plan p = plan_canonical(mode, data, n, abs_offset, sps);
   return sim_run(mode, data, n, p.in0_base, p.scan_lo, p.scan_hi, p.fall_hi, p.dem_hi, p.origin, thr, p.prev_in0, sps,
-                 p.end_is_call_end, p.prev_eob_stream, 1, 0, grid_max, rec_cap, out, out_cap, so);
+                 p.end_is_call_end, p.prev_eob_stream, 1, 0, grid_max, rec_cap, scale, out, out_cap, so);
 }
 
 // state[0] = prev_in0 (float bits in a double), state[1] = prev_eob
@@ -110,7 +114,7 @@ int sim_framer_work(const float* in0, long long n_in0, long long N, long long ni
   st.prev_in0 = *prev_in0; st.prev_eob = *prev_eob;
   Plan p = plan_framer_work(in0, n_in0, N, nitems_written, sps, st);
   int rc = sim_run(1, in0, n_in0, p.in0_base, p.scan_lo, p.scan_hi, p.fall_hi, p.dem_hi, p.origin, thr, p.prev_in0, sps,
-                   p.end_is_call_end, p.prev_eob_stream, 1, 0, grid_max, 0, out, out_cap, so);
+                   p.end_is_call_end, p.prev_eob_stream, 1, 0, grid_max, 0, 1.0f, out, out_cap, so);
   if (rc) return rc;
   framer_state_update(st, in0[N - 1], N, sps, so->flags, so->lastp, kNoIndex, so->n_kept,
                       so->n_kept > 0 ? so->last_kept : 0);
@@ -123,7 +127,7 @@ int sim_shard(int mode, const float* data, long long n, long long origin, long l
               SimOut* so) {
   Plan p = plan_shard(mode, data, n, origin, own_lo, own_hi, stream_len, sps, head_n);
   return sim_run(mode, data, n, p.in0_base, p.scan_lo, p.scan_hi, p.fall_hi, p.dem_hi, p.origin, thr, p.prev_in0, sps,
-                 p.end_is_call_end, p.prev_eob_stream, p.gate ? 1 : 0, p.head_n, grid_max, 0, out, out_cap, so);
+                 p.end_is_call_end, p.prev_eob_stream, p.gate ? 1 : 0, p.head_n, grid_max, 0, 1.0f, out, out_cap, so);
 }
 
 // k_slice for a tag list (demod block emulation)

@@ -44,9 +44,14 @@ def lib():
 
 
 def sim_run(mode, data, sps, thr, in0_base, scan_lo, scan_hi, fall_hi, dem_hi, origin=0, prev_in0=0.0,
-            end_is_call_end=1, prev_eob_stream=None, gate=True, grid_max=6, rec_cap=0):
-    data = np.ascontiguousarray(data, dtype=np.complex64 if mode == 0 else np.float32)
-    n = len(data)
+            end_is_call_end=1, prev_eob_stream=None, gate=True, grid_max=6, rec_cap=0, scale=1.0):
+    """mode 0: complex64[n]; 1: float32 |IQ|^2 [n]; 2: int16 interleaved IQ [2n]."""
+    if mode == 2:
+        data = np.ascontiguousarray(data, dtype=np.int16)
+        n = len(data) // 2
+    else:
+        data = np.ascontiguousarray(data, dtype=np.complex64 if mode == 0 else np.float32)
+        n = len(data)
     if prev_eob_stream is None:
         prev_eob_stream = origin + in0_base - 1
     cap = max(16, n // 2 + 16)
@@ -57,6 +62,7 @@ def sim_run(mode, data, sps, thr, in0_base, scan_lo, scan_hi, fall_hi, dem_hi, o
                        c.c_longlong(scan_lo), c.c_longlong(scan_hi), c.c_longlong(fall_hi), c.c_longlong(dem_hi),
                        c.c_longlong(origin), c.c_float(thr), c.c_float(prev_in0), c.c_int(sps), c.c_int(end_is_call_end),
                        c.c_longlong(prev_eob_stream), c.c_int(1 if gate else 0), c.c_int(0), c.c_int(grid_max), c.c_int(rec_cap),
+                       c.c_float(scale),
                        out.ctypes.data_as(c.c_void_p), c.c_int(cap), c.byref(so))
     assert rc == 0
     return out[:so.n_kept].copy(), so
@@ -65,7 +71,7 @@ def sim_run(mode, data, sps, thr, in0_base, scan_lo, scan_hi, fall_hi, dem_hi, o
 def sim_canonical(mode, data, fs, thr, abs_offset=0, **kw):
     sps = int(fs // 1e6)
     H = 8 * sps
-    n = len(data)
+    n = len(data) // 2 if mode == 2 else len(data)
     return sim_run(mode, data, sps, thr, in0_base=-(H - 1), scan_lo=-(H - 1), scan_hi=n - (H - 1), fall_hi=n - (H - 1),
                    dem_hi=n, origin=abs_offset, **kw)
 

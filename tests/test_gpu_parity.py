@@ -42,6 +42,34 @@ def test_canonical_host_iq_matches_reference_goldens(native, name):
 
 
 @pytest.mark.parametrize("name", golden_names())
+def test_canonical_int16_iq_matches_reference_goldens(native, torch_mod, name):
+    g = Golden(name)
+    ctx = native.Context(g.fs, g.thr)
+    ctx.set_iq16_scale(2.0 / 32767.0)
+    q = g.z["iq16"]
+    assert_recs_match_golden(ctx.process_iq16(q), g)
+    t = torch_mod.from_numpy(q.copy()).to("cuda:0")
+    assert_recs_match_golden(ctx.process_iq16_device(t.data_ptr(), len(q) // 2), g)
+    tk = ctx.submit_iq16_device(t.data_ptr(), len(q) // 2)
+    assert_recs_match_golden(ctx.wait(tk), g)
+
+
+def test_int16_iq_large_vs_c_oracle(native, torch_mod):
+    from gr_adsb_amd import modulator as M
+    from oracle import adsb_oracle as O
+    from oracle import c_oracle as C
+    n = 1 << 22
+    q = M.quantize_iq16(M.synth_iq(n, 8e6, 6000, 9), full_scale=4.0)
+    scale = 4.0 / 32767.0
+    ctx = native.Context(8e6, 0.01)
+    ctx.set_iq16_scale(scale)
+    got = ctx.process_iq16(q)
+    want = C.canonical(O.mag2_iq16(q, scale), 8, 0.01)
+    assert len(want) > 1000
+    assert_recs_equal(got, want, "int16 IQ")
+
+
+@pytest.mark.parametrize("name", golden_names())
 @pytest.mark.parametrize("sched", SCHEDULES)
 def test_dropin_blocks_match_reference_goldens(native, name, sched):
     """The reference's own block API, driven work() call by work() call with the golden's chunk schedule."""

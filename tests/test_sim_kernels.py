@@ -24,6 +24,16 @@ def test_canonical_matches_goldens(name, mode):
     assert np.all((recs["flags"] & 2) != 0)
 
 
+@pytest.mark.parametrize("name", golden_names())
+def test_canonical_int16_iq_matches_goldens(name):
+    """The fixtures ARE int16 IQ; the int16 input format must reproduce the reference on them directly."""
+    g = Golden(name)
+    scale = float(np.float32(2.0 / 32767.0))
+    assert np.array_equal(O.mag2_iq16(g.z["iq16"], scale), g.x)
+    recs, so = simlib.sim_canonical(2, g.z["iq16"], g.fs, g.thr, scale=scale)
+    assert_recs_match_golden(recs, g)
+
+
 @pytest.mark.parametrize("name", ["g2msps_df17", "g8msps_dense", "g2msps_mixed_lowsnr"])
 @pytest.mark.parametrize("sched", ["fixed4096", "random"])
 def test_framer_work_chunked_matches_goldens(name, sched):

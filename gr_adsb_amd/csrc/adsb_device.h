@@ -18,8 +18,8 @@
 //   PPM slice                     demod.py:75-95        confidence ratio  demod.py:101
 //
 // This header contains device code only and includes nothing.  The includer provides the HIP device
-// environment plus `adsb_wave_sync()` (a wavefront-level execution/LDS ordering point) and `adsb_uniform(int)`
-// (marks a wavefront-uniform value so it lives in a scalar register): the product translation unit adsb_hip.hip
+// environment plus `adsb_wave_sync()` (a wavefront-level execution/LDS ordering point), `adsb_uniform(int)`
+// (marks a wavefront-uniform value so it lives in a scalar register) and `adsb_readlane(int, lane)`: the product translation unit adsb_hip.hip
 // maps them to __builtin_amdgcn_wave_barrier() / __builtin_amdgcn_readfirstlane(); tests/sim/sim_driver.cpp
 // includes the test-only SIMT emulator instead so the very same kernels run on a machine without a GPU.
 #pragma once
@@ -48,6 +48,18 @@ static_assert(kQWords == 16, "word owners are lanes 0..15 of each wavefront");
 #define ADSB_ABLATE 0
 #endif
 constexpr int kAblate = ADSB_ABLATE;
+// Experiment switch: stage complex64 with 8-byte loads (one sample per lane: the threshold ballot is already
+// in natural order) instead of 16-byte loads (two samples per lane + an even/odd re-interleave).
+#ifndef ADSB_LOAD8
+#define ADSB_LOAD8 0
+#endif
+constexpr bool kLoad8 = ADSB_LOAD8 != 0;
+// Experiment switch: fetch the next tile AFTER this tile's compute phases (staging registers are then dead
+// during the phases: fewer VGPRs, more resident workgroups hide the fetch instead of software prefetch).
+#ifndef ADSB_LATE_ISSUE
+#define ADSB_LATE_ISSUE 0
+#endif
+constexpr bool kLateIssue = ADSB_LATE_ISSUE != 0;
 // k_detect is latency bound per workgroup: 5 resident workgroups per CU (<= 96 VGPRs, no spills) measured
 // 15-20 % faster than 4; 6 would need spills to scratch.
 #ifndef ADSB_MIN_WAVES
@@ -259,14 +271,19 @@ __device__ void emit_record(const DetectArgs& a, long long p, unsigned xflags, R
 // into |IQ|^2 floats in LDS AND into the natural-order threshold bitmask words of those samples
 // (span_commit) -- so the fetch of tile k+1 is in flight while tile k is processed, and the threshold
 // masks cost no LDS re-read.  The fast path (whole span inside the buffer) has no per-load branches.
+template <bool C, class A, class B> struct Pick { using type = A; };
+template <class A, class B> struct Pick<false, A, B> { using type = B; };
+
 template <int MODE, int COUNT>
 struct Span {
-  static constexpr int PER = (MODE == 0) ? 2 : 4;             // samples per 16-byte load (complex64: 2; float / int16 IQ: 4)
+  static constexpr bool L8 = (MODE == 0) && kLoad8;           // 8-byte loads, 1 sample per lane
+  static constexpr int PER = L8 ? 1 : (MODE == 0) ? 2 : 4;    // samples per load (complex64: 2; float / int16 IQ: 4)
   static constexpr int SHARE = COUNT / kWaves;                // samples per wavefront
   static constexpr int GROUP = 64 * PER;                      // samples per wave-wide load
   static constexpr int ITER = (SHARE + GROUP - 1) / GROUP;    // (a partial last group only for the head span)
   static constexpr int LANES = (SHARE < GROUP) ? SHARE / PER : 64;   // active lanes when SHARE < GROUP
-  float4 q[ITER];
+  using Q = typename Pick<L8, float2, float4>::type;
+  Q q[ITER];
 };
 
 // Returns false (wave- and block-uniform) when the span is not entirely inside the buffer: the caller
@@ -279,11 +296,12 @@ __device__ __forceinline__ bool span_issue(Span<MODE, COUNT>& sp, const DetectAr
   const long long wsrc = src + (long long)wave * S::SHARE;
   constexpr int BPS = (MODE == 0) ? 8 : 4;                    // bytes per sample
   const char* ub = reinterpret_cast<const char*>(a.data) + wsrc * BPS;
-  const unsigned lo = (unsigned)lane * 16u;
+  using Q = typename S::Q;
+  const unsigned lo = (unsigned)lane * (unsigned)sizeof(Q);
 #pragma unroll
   for (int k = 0; k < S::ITER; ++k) {
-    if (S::LANES == 64 || lane < S::LANES) sp.q[k] = *reinterpret_cast<const float4*>(ub + (k * 1024 + lo));
-    else { sp.q[k].x = sp.q[k].y = sp.q[k].z = sp.q[k].w = 0.0f; }
+    if (S::LANES == 64 || lane < S::LANES) sp.q[k] = *reinterpret_cast<const Q*>(ub + (k * 64 * (int)sizeof(Q) + lo));
+    else sp.q[k] = Q{};
   }
   return true;
 }
@@ -314,7 +332,14 @@ __device__ __forceinline__ void span_commit(const Span<MODE, COUNT>& sp, float* 
 #pragma unroll
   for (int k = 0; k < S::ITER; ++k) {
     const int g = wdst + k * S::GROUP;                        // first LDS sample of this wave-wide group
-    if (MODE == 0) {
+    if constexpr (S::L8) {
+      const float m = mag2f(sp.q[k].x, sp.q[k].y);
+      sx[g + lane] = m;
+      if (kAblate < 3) {
+        const unsigned long long w0 = __ballot(m >= thr);     // one sample per lane: already in natural order
+        if (lane == 0) smask[g >> 6] = w0;
+      }
+    } else if constexpr (MODE == 0) {
       float2 m;
       m.x = mag2f(sp.q[k].x, sp.q[k].y);
       m.y = mag2f(sp.q[k].z, sp.q[k].w);
@@ -410,8 +435,8 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
     //       (floats + mask words 4..67), then start fetching the next body so it is in flight below
     if (!body_ok) span_fill_ragged<MODE, kTile>(s_x, s_mask, kFwd, a, t0 + kFwd);
     else if (kAblate < 4) span_commit<MODE, kTile>(body, s_x, s_mask, kFwd, a.thr, a.scale, wave, lane);
-    else { float acc = 0.0f; for (int k = 0; k < Span<MODE, kTile>::ITER; ++k) acc += body.q[k].x + body.q[k].w; if (acc == 123.456f) s_x[tid] = acc; }
-    if (t0 + kTile < c1) body_ok = span_issue<MODE, kTile>(body, a, t0 + kTile + kFwd, wave, lane);
+    else { float acc = 0.0f; for (int k = 0; k < Span<MODE, kTile>::ITER; ++k) acc += body.q[k].x + body.q[k].y; if (acc == 123.456f) s_x[tid] = acc; }
+    if (!kLateIssue && t0 + kTile < c1) body_ok = span_issue<MODE, kTile>(body, a, t0 + kTile + kFwd, wave, lane);
     __syncthreads();
 
     // -- B: every wavefront handles the rises of its own 16 mask words, no cross-wave sync inside
@@ -427,20 +452,23 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
       unsigned long long R = M & ~sh & own;
       const unsigned long long Fm = ~M & sh & own;
       const unsigned long long anyr = __ballot(R != 0ull), anyf = __ballot(Fm != 0ull);
+      if (lane == 0) { s_wflags[wave] = (anyr ? 1 : 0) | (anyf ? 2 : 0); s_wlastp[wave] = -1; }
+      // exclusive prefix of the 16 word counts with scalar lane reads (no LDS round trips)
       const int cnt = __popcll(R);
-      int incl = cnt;
-      for (int d = 1; d < 16; d <<= 1) {
-        const int t = __shfl_up(incl, (unsigned)d);
-        if (lane >= d) incl += t;
+      int pos = 0, nr = 0;
+      if (anyr) {                                          // wave-uniform: quiet stretches skip everything below
+#pragma unroll
+        for (int j = 0; j < kQWords; ++j) {
+          const int cj = adsb_readlane(cnt, j);
+          if (lane > j) pos += cj;
+          nr += cj;
+        }
+        while (R) {
+          const int b = __builtin_ctzll(R);
+          R &= R - 1ull;
+          s_rise[wave][pos++] = (unsigned short)(64 * word + b);
+        }
       }
-      int pos = incl - cnt;
-      const int nr = __shfl(incl, 15);
-      while (R) {
-        const int b = __builtin_ctzll(R);
-        R &= R - 1ull;
-        s_rise[wave][pos++] = (unsigned short)(64 * word + b);
-      }
-      if (lane == 0) s_wflags[wave] = (anyr ? 1 : 0) | (anyf ? 2 : 0);
       adsb_wave_sync();
 
       // B.2 per rise: fall, centre, 16-chip test (framer.py:113,137-147)
@@ -485,7 +513,7 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
         s_rise[wave][i] = res;
       }
       // last paired centre of this wavefront's quarter and halo flag -> one LDS word per wavefront
-      {
+      if (nre > 0) {
         const unsigned long long m1 = __ballot(lp >= 0), m2 = __ballot(lp2 >= 0), mh = __ballot(hflag != 0);
         const int v1 = __shfl(lp, m1 ? __builtin_ctzll(m1) : 0);
         const int v2 = __shfl(lp2, m2 ? __builtin_ctzll(m2) : 0);
@@ -493,8 +521,8 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
           s_wlastp[wave] = m1 ? v1 : (m2 ? v2 : -1);
           if (mh) s_wflags[wave] |= 4;
         }
+        adsb_wave_sync();
       }
-      adsb_wave_sync();
 
       // B.3 ordered in-place compaction of this wavefront's matched centres
       for (int base = 0; base < nre; base += 64) {
@@ -553,6 +581,7 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
 #pragma unroll
       for (int w = 0; w < kWaves; ++w) { if (s_wlastp[w] >= 0) wl = s_wlastp[w]; wf |= (unsigned)s_wflags[w]; }
     }
+    if (kLateIssue && t0 + kTile < c1) body_ok = span_issue<MODE, kTile>(body, a, t0 + kTile + kFwd, wave, lane);
     __syncthreads();
     s_x[tid] = keep;
     if (tid < kHeadWords) s_mask[tid] = keepm;
@@ -620,42 +649,69 @@ __global__ void __launch_bounds__(kThreads) k_longrun(DetectArgs a) {
   }
 }
 
+// Exclusive prefix sum of one int per thread over a 256-thread workgroup (wave shuffles + 4 LDS words).
+// Every thread must call it; *total receives the sum on every thread.
+__device__ __forceinline__ int block_excl_scan(int v, int* total) {
+  __shared__ int s_wsum[kWaves];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, (unsigned)d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) s_wsum[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) {
+    const int c = s_wsum[w];
+    if (w < wave) base += c;
+    tot += c;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
 // ---- k_scan: per-workgroup counts -> offsets, totals (single workgroup) ----------------------------
 __global__ void __launch_bounds__(kThreads) k_scan(const int* blk_count, const long long* blk_lastp,
                                                    const unsigned* blk_flags, int nblk, int rec_cap,
                                                    const int* long_count, const unsigned long long* long_lastp,
                                                    int* blk_off, Summary* sum) {
-  __shared__ int s_part[kThreads];
-  __shared__ long long s_lp[kThreads];
-  __shared__ unsigned s_fl[kThreads];
-  __shared__ int s_ovf[kThreads];
-  const int tid = threadIdx.x;
+  __shared__ long long s_lp[kWaves];
+  __shared__ unsigned s_fl[kWaves];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (nblk + kThreads - 1) / kThreads;
   const int b0 = tid * per;
   int b1 = b0 + per; if (b1 > nblk) b1 = nblk;
-  int acc = 0, ovf = 0; long long lp = kNoIndex; unsigned fl = 0;
+  int acc = 0; long long lp = kNoIndex; unsigned fl = 0;
   for (int b = b0; b < b1; ++b) {
     int c = blk_count[b];
-    if (c > rec_cap) { ovf = 1; c = rec_cap; }
+    if (c > rec_cap) { fl |= 0x80000000u; c = rec_cap; }      // bit 31: some workgroup overflowed its list
     acc += c;
     const long long l = blk_lastp[b];
     if (l > lp) lp = l;
     fl |= blk_flags[b];
   }
-  s_part[tid] = acc; s_lp[tid] = lp; s_fl[tid] = fl; s_ovf[tid] = ovf;
-  __syncthreads();
+  // workgroup reductions: max of lastp, OR of flags (wave shuffles, then 4 words)
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const long long ol = __shfl_xor(lp, d);
+    const unsigned of = __shfl_xor(fl, d);
+    if (ol > lp) lp = ol;
+    fl |= of;
+  }
+  if (lane == 0) { s_lp[wave] = lp; s_fl[wave] = fl; }
+  int total = 0;
+  int run = block_excl_scan(acc, &total);                      // contains the barriers that publish s_lp / s_fl
   if (tid == 0) {
-    int run = 0; long long L = (*long_lastp == 0ull) ? kNoIndex : (long long)(*long_lastp) - (1ll << 62); unsigned F = 0; int O = 0;
-    for (int t = 0; t < kThreads; ++t) {
-      const int c = s_part[t]; s_part[t] = run; run += c;
-      if (s_lp[t] > L) L = s_lp[t];
-      F |= s_fl[t]; O |= s_ovf[t];
-    }
-    sum->n_rec = run; sum->overflow = O; sum->flags = F; sum->lastp = L;
+    long long L = (*long_lastp == 0ull) ? kNoIndex : (long long)(*long_lastp) - (1ll << 62);
+    unsigned F = 0;
+    for (int w = 0; w < kWaves; ++w) { if (s_lp[w] > L) L = s_lp[w]; F |= s_fl[w]; }
+    sum->n_rec = total; sum->overflow = (F >> 31) & 1u; sum->flags = F & 0x7FFFFFFFu; sum->lastp = L;
     sum->long_count = *long_count; sum->n_kept = 0; sum->last_kept_p = kNoIndex;
   }
-  __syncthreads();
-  int run = s_part[tid];
   for (int b = b0; b < b1; ++b) {
     int c = blk_count[b];
     if (c > rec_cap) c = rec_cap;
@@ -746,7 +802,6 @@ __global__ void __launch_bounds__(kThreads) k_count(const unsigned long long* so
 
 __global__ void __launch_bounds__(kThreads) k_scan2(int* seg_count, Summary* sum) {
   // exclusive scan of seg_count in place (single workgroup) + total
-  __shared__ int s_part[kThreads];
   const int n = sum->n_rec;
   const int nseg = (n + kThreads - 1) / kThreads;
   const int tid = threadIdx.x;
@@ -755,15 +810,9 @@ __global__ void __launch_bounds__(kThreads) k_scan2(int* seg_count, Summary* sum
   int b1 = b0 + per; if (b1 > nseg) b1 = nseg;
   int acc = 0;
   for (int b = b0; b < b1; ++b) acc += seg_count[b];
-  s_part[tid] = acc;
-  __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int t = 0; t < kThreads; ++t) { const int c = s_part[t]; s_part[t] = run; run += c; }
-    sum->n_kept = run;
-  }
-  __syncthreads();
-  int run = s_part[tid];
+  int total = 0;
+  int run = block_excl_scan(acc, &total);
+  if (tid == 0) sum->n_kept = total;
   for (int b = b0; b < b1; ++b) { const int c = seg_count[b]; seg_count[b] = run; run += c; }
 }
 

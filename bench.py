@@ -71,8 +71,8 @@ def cpu_baseline(iq_host, sps, thr, reps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--fs", type=float, default=2e6)
     ap.add_argument("--log2n", type=int, default=28, help="log2 of complex samples per GPU per step")
     ap.add_argument("--bursts", type=float, default=1000.0, help="bursts per second of signal")
@@ -224,6 +224,7 @@ def main():
                 "fs": fs, "samples_per_gpu_per_step": n_own, "bursts_per_step_rank0": int(n_bursts),
                 "sharding": "none" if n_gpus == 1 else "%d overlapped time shards, host stitch" % n_gpus,
                 "pipeline": "2 passes in flight (submit/wait)",
+                "detect_gap_ms_avg": round(st["detect_gap_ms"] / max(1, st["detect_gaps"]), 4),
                 "detect_grid": int(st["detect_grid"]), "retries": int(st["retries"]), "longrun_calls": int(st["longrun_calls"]),
             },
             "roofline": {

@@ -800,7 +800,8 @@ __global__ void __launch_bounds__(kThreads) k_count(const unsigned long long* so
   }
 }
 
-__global__ void __launch_bounds__(kThreads) k_scan2(int* seg_count, Summary* sum) {
+__global__ void __launch_bounds__(kThreads) k_scan2(int* seg_count, Summary* sum, int* long_count,
+                                                    unsigned long long* long_lastp) {
   // exclusive scan of seg_count in place (single workgroup) + total
   const int n = sum->n_rec;
   const int nseg = (n + kThreads - 1) / kThreads;
@@ -812,7 +813,11 @@ __global__ void __launch_bounds__(kThreads) k_scan2(int* seg_count, Summary* sum
   for (int b = b0; b < b1; ++b) acc += seg_count[b];
   int total = 0;
   int run = block_excl_scan(acc, &total);
-  if (tid == 0) sum->n_kept = total;
+  if (tid == 0) {
+    sum->n_kept = total;
+    *long_count = 0;        // k_scan has consumed the long-pulse list: leave it empty for the slot's next pass
+    *long_lastp = 0ull;
+  }
   for (int b = b0; b < b1; ++b) { const int c = seg_count[b]; seg_count[b] = run; run += c; }
 }
 

@@ -56,6 +56,7 @@ struct Slot {
   hipEvent_t done = nullptr, ev0 = nullptr, ev1 = nullptr, det_done = nullptr;
   bool busy = false;
   bool is_shard = false;
+  bool ev1_valid = false;
   Plan plan{};
   DetectArgs args{};
   int grid = 0, rec_cap = 0;
@@ -137,8 +138,8 @@ void launch_burst(adsb_ctx* c, hipStream_t st, const DetectArgs& a, const unsign
   hipLaunchKernelGGL((k_burst<MODE>), dim3(c->n_cu * 8), dim3(kThreads), 0, st, a, kept, sum, out, cap);
 }
 template <int MODE>
-void launch_longrun(adsb_ctx* c, const DetectArgs& a) {
-  hipLaunchKernelGGL((k_longrun<MODE>), dim3(64), dim3(kThreads), 0, c->stream, a);
+void launch_longrun(hipStream_t st, const DetectArgs& a) {
+  hipLaunchKernelGGL((k_longrun<MODE>), dim3(64), dim3(kThreads), 0, st, a);
 }
 
 // Everything after k_detect (and after k_longrun on the rare second pass): order, gate, compact, records.
@@ -154,6 +155,8 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
     HIPCHK(c, hipStreamWaitEvent(c->tail_stream, s.det_done, 0));
     ts = c->tail_stream;
   }
+  // no-op unless k_detect listed pulses longer than its LDS window
+  if (pl.mode == 0) launch_longrun<0>(ts, a); else if (pl.mode == 1) launch_longrun<1>(ts, a); else launch_longrun<2>(ts, a);
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(kThreads), 0, ts, (const int*)a.blk_count,
                      (const long long*)a.blk_lastp, (const unsigned*)a.blk_flags, s.grid, s.rec_cap,
                      (const int*)a.long_count, (const unsigned long long*)a.long_lastp, (int*)s.d_blk_off.p, &misc->sum);
@@ -171,7 +174,7 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   }
   hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted,
                      (const Summary*)&misc->sum, fmask, fwant, pl.head_n, (int*)s.d_seg.p);
-  hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kThreads), 0, ts, (int*)s.d_seg.p, &misc->sum);
+  hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kThreads), 0, ts, (int*)s.d_seg.p, &misc->sum, a.long_count, a.long_lastp);
   hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted, &misc->sum,
                      (const int*)s.d_seg.p, fmask, fwant, pl.head_n, kept, (int)s.tot);
   if (pl.mode == 0) launch_burst<0>(c, ts, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
@@ -211,7 +214,10 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   if ((r = ensure(c, s.d_blk_flags, (size_t)grid * sizeof(unsigned)))) return r;
   if ((r = ensure(c, s.d_blk_off, (size_t)grid * sizeof(int)))) return r;
   if ((r = ensure(c, s.d_long, (size_t)long_cap * sizeof(LongRise)))) return r;
-  if ((r = ensure(c, s.d_misc, sizeof(Misc)))) return r;
+  if (!s.d_misc.p) {
+    if ((r = ensure(c, s.d_misc, sizeof(Misc)))) return r;
+    HIPCHK(c, hipMemset(s.d_misc.p, 0, sizeof(Misc)));   // afterwards k_scan2 re-zeroes the list head every pass
+  }
   Misc* misc = (Misc*)s.d_misc.p;
 
   DetectArgs& a = s.args;
@@ -222,12 +228,10 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   a.blk_lastp = (long long*)s.d_blk_lastp.p; a.blk_flags = (unsigned*)s.d_blk_flags.p;
   a.longlist = (LongRise*)s.d_long.p; a.long_count = &misc->long_count; a.long_lastp = &misc->long_lastp;
 
-  HIPCHK(c, hipMemsetAsync(misc, 0, 16, c->stream));
   const bool timing = (c->flags & ADSB_FLAG_TIMING) != 0;
   if (timing) HIPCHK(c, hipEventRecord(s.ev0, c->stream));
   if (pl.mode == 0) launch_detect<0>(c, a, grid); else if (pl.mode == 1) launch_detect<1>(c, a, grid); else launch_detect<2>(c, a, grid);
   if (timing) HIPCHK(c, hipEventRecord(s.ev1, c->stream));
-  if (pl.mode == 0) launch_longrun<0>(c, a); else if (pl.mode == 1) launch_longrun<1>(c, a); else launch_longrun<2>(c, a);   // no-op unless k_detect listed long pulses
   c->stats.detect_grid = (uint64_t)grid; c->stats.blocks_per_cu = (uint64_t)c->bpc[pl.mode];
   c->stats.calls++;
   s.busy = true;
@@ -247,6 +251,15 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
       HIPCHK(c, hipEventElapsedTime(&ms, s.ev0, s.ev1));
       c->stats.detect_launches++;
       c->stats.detect_ms += ms;
+      // idle time on the compute stream between the previous pass's k_detect and this one (pipelined use)
+      Slot& prev = c->slot[(&s == &c->slot[0]) ? 1 : 0];
+      if (prev.ev1_valid) {
+        float gap = 0;
+        if (hipEventElapsedTime(&gap, prev.ev1, s.ev0) == hipSuccess && gap >= 0 && gap < 100.0f) {
+          c->stats.detect_gap_ms += gap; c->stats.detect_gaps++;
+        } else (void)hipGetLastError();
+      }
+      s.ev1_valid = true;
       c->stats.detect_samples += (uint64_t)s.span;
       c->stats.detect_bytes += (uint64_t)s.span * (s.plan.mode == 0 ? 8u : 4u);
     }

@@ -63,6 +63,8 @@ typedef struct adsb_stats {
   uint64_t longrun_calls;    /* calls that needed the long-pulse kernel */
   uint64_t detect_grid;      /* workgroups of the last k_detect launch */
   uint64_t blocks_per_cu;    /* resident k_detect workgroups per CU (occupancy query) */
+  double detect_gap_ms;      /* sum of idle gaps on the compute stream between consecutive timed k_detect launches */
+  uint64_t detect_gaps;      /* number of gaps summed */
 } adsb_stats;
 
 int adsb_abi_version(void);

@@ -78,7 +78,7 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     }
     hipsim::launch(k_count, 3, kThreads, (const unsigned long long*)sorted.data(), (const Summary*)&sum, fmask, fwant,
                    head_n, seg.data());
-    hipsim::launch(k_scan2, 1, kThreads, seg.data(), &sum);
+    hipsim::launch(k_scan2, 1, kThreads, seg.data(), &sum, &long_count, &long_lastp);
     hipsim::launch(k_compact, 3, kThreads, (const unsigned long long*)sorted.data(), &sum, (const int*)seg.data(),
                    fmask, fwant, head_n, kept.data(), (int)tot);
     if (mode == 0) hipsim::launch(k_burst<0>, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum,

@@ -141,11 +141,21 @@ def main():
             return collect_shard(pending.pop(0))
         return 0
 
+    stash = {}            # results of tickets that had to be collected early (fallback path only)
+
+    def ungated():
+        # fallback of sharding.finish_shard: a blocking call is only allowed with no ticket pending, so
+        # collect (and keep) whatever is still in flight first; every rank takes this path together
+        for t in list(pending):
+            stash[t] = fe.wait(t)
+        return fe.shard_tensor(iq, plan["lo"], plan["own_lo"], plan["own_hi"], stream_len)
+
     def collect_shard(ticket):
-        recs = fe.wait(ticket, copy=False)          # view of the pinned result buffer, fixed up in place
-        kept = sharding.finish_shard(recs, sps, rank, ag_int,
-                                     lambda: fe.shard_tensor(iq, plan["lo"], plan["own_lo"], plan["own_hi"], stream_len),
-                                     ag_obj, inplace=True)
+        if ticket in stash:
+            recs, inplace = stash.pop(ticket), False
+        else:
+            recs, inplace = fe.wait(ticket, copy=False), True    # view of the pinned result buffer, fixed up in place
+        kept = sharding.finish_shard(recs, sps, rank, ag_int, ungated, ag_obj, inplace=inplace)
         return len(kept)
 
     def ag_int(v):

@@ -285,3 +285,24 @@ def test_full_size_properties(native, torch_mod):
         assert (a["offset"] >= c0).sum() > 1000
     lists = [fe.shard_tensor(iq[p["lo"]:p["hi"]], p["lo"], p["own_lo"], p["own_hi"], n) for p in shard_plan(n, 8, sps)]
     assert fe.stitch(lists).tobytes() == whole.tobytes()
+
+
+def test_adversarial_streams(native):
+    """The seam-hunting streams of test_sim_property.py (plateaus and bursts planted on tile / window
+    boundaries, exact ties, thresholds on sample values, NaNs) through the real kernels."""
+    from test_sim_property import adversarial_stream
+    from oracle import c_oracle as C
+    ctxs = {}
+    checked = 0
+    for seed in range(120):
+        rng = np.random.default_rng(seed)
+        n = int(rng.choice([1, 17, 240, 4095, 4096, 4097, 4111, 4352, 8191, 8192, 8193, 12288, 20000, 70000]))
+        sps = int(rng.choice([2, 4, 8, 20]))
+        thr = float(rng.choice([0.01, 0.0099, 0.0101, 0.004, 0.05]))
+        x = adversarial_stream(rng, n, sps)
+        ctx = ctxs.setdefault(sps, native.Context(sps * 1e6, thr))
+        ctx.set_threshold(thr)
+        want = C.canonical(x, sps, thr)
+        assert_recs_equal(ctx.process_mag2(x), want, "seed %d" % seed)
+        checked += len(want)
+    assert checked > 100

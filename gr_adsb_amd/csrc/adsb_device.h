@@ -1,7 +1,7 @@
 // adsb_device.h -- CDNA4 (gfx950) device code for the ADS-B front end.
 //
 //   k_detect   streams the IQ once: |IQ|^2 -> threshold bitmask (one __ballot per 64 samples) -> rises by
-//              mask algebra -> pulse centre -> 16-chip preamble test; emits matched centres per workgroup
+//              mask algebra -> pulse centre -> 16-chip preamble test; emits matched centres per wavefront
 //   k_longrun  (rare) pulses longer than the LDS window
 //   k_scan / k_gather / k_resolve / k_count / k_scan2 / k_compact
 //              order the centres, apply the re-trigger gate as parallel chain walks, compact
@@ -19,28 +19,26 @@
 //
 // This header contains device code only and includes nothing.  The includer provides the HIP device
 // environment plus `adsb_wave_sync()` (a wavefront-level execution/LDS ordering point), `adsb_uniform(int)`
-// (marks a wavefront-uniform value so it lives in a scalar register) and `adsb_readlane(int, lane)`: the product translation unit adsb_hip.hip
-// maps them to __builtin_amdgcn_wave_barrier() / __builtin_amdgcn_readfirstlane(); tests/sim/sim_driver.cpp
-// includes the test-only SIMT emulator instead so the very same kernels run on a machine without a GPU.
+// (marks a wavefront-uniform value so it lives in a scalar register) and `adsb_readlane(int, lane)`: the
+// product translation unit adsb_hip.hip maps them to __builtin_amdgcn_wave_barrier() / _readfirstlane() /
+// _readlane(); tests/sim/sim_driver.cpp includes the test-only SIMT emulator instead, so the very same
+// kernels run on a machine without a GPU.
 #pragma once
 
 namespace adsb {
 
 constexpr int kThreads = 256;            // 4 wavefronts per workgroup
 constexpr int kWaves = kThreads / 64;
-constexpr int kTile = 4096;              // samples owned per tile iteration (64 ballot words)
+constexpr int kWTile = 1024;             // samples a wavefront owns per tile iteration (16 ballot words)
 constexpr int kFwd = 256;                // forward halo kept in LDS behind every tile
-constexpr int kWin = kTile + kFwd;
-constexpr int kWords = kWin / 64;        // 68
-constexpr int kOwnWords = kTile / 64;    // 64
-constexpr int kQuarter = kTile / kWaves; // samples a wavefront stages and owns per tile
-constexpr int kQWords = kQuarter / 64;   // 16
+constexpr int kWWin = kWTile + kFwd;
+constexpr int kWWords = kWWin / 64;      // 20
+constexpr int kWOwn = kWTile / 64;       // 16: word owners are lanes 0..15
 constexpr int kHeadWords = kFwd / 64;    // 4
 constexpr unsigned kTemplate = 0x285u;   // chips 0,2,7,9 high (framer.py:50)
 constexpr int kNoise = 100;              // framer.py:31
 constexpr long long kNoIndex = -(1ll << 62);
-static_assert(kFwd == kThreads, "the halo shift moves one float per thread");
-static_assert(kQWords == 16, "word owners are lanes 0..15 of each wavefront");
+static_assert(kWOwn == 16 && kFwd % 64 == 0, "word owners are lanes 0..15 of each wavefront");
 
 // Tuning aid (tools/kbench.py builds side copies of the library with -DADSB_ABLATE=k to time phases of
 // k_detect in isolation); the shipped library is always built with 0 = nothing skipped.
@@ -48,18 +46,9 @@ static_assert(kQWords == 16, "word owners are lanes 0..15 of each wavefront");
 #define ADSB_ABLATE 0
 #endif
 constexpr int kAblate = ADSB_ABLATE;
-// Experiment switch: stage complex64 with 8-byte loads (one sample per lane: the threshold ballot is already
-// in natural order) instead of 16-byte loads (two samples per lane + an even/odd re-interleave).
-#ifndef ADSB_LOAD8
-#define ADSB_LOAD8 0
+#ifndef ADSB_TAP_UNROLL
+#define ADSB_TAP_UNROLL 16
 #endif
-constexpr bool kLoad8 = ADSB_LOAD8 != 0;
-// Experiment switch: fetch the next tile AFTER this tile's compute phases (staging registers are then dead
-// during the phases: fewer VGPRs, more resident workgroups hide the fetch instead of software prefetch).
-#ifndef ADSB_LATE_ISSUE
-#define ADSB_LATE_ISSUE 0
-#endif
-constexpr bool kLateIssue = ADSB_LATE_ISSUE != 0;
 // k_detect is latency bound per workgroup: 5 resident workgroups per CU (<= 96 VGPRs, no spills) measured
 // 15-20 % faster than 4; 6 would need spills to scratch.
 #ifndef ADSB_MIN_WAVES
@@ -110,18 +99,18 @@ struct DetectArgs {
   long long fall_hi;     // a pulse needs its fall at an index < fall_hi
   long long dem_hi;      // PPM-slice iff p + 119*sps + sps/2 < dem_hi
   long long origin;      // stream offset of local index 0
-  long long chunk;       // samples per workgroup (multiple of kTile)
+  long long chunk;       // samples per unit (= wavefront), multiple of kWTile
   float thr;
   float prev_in0;        // value compared for the sample before in0[0] (framer.py:84)
   float scale;           // MODE 2: float32 multiplier applied to every int16 component
   int sps;
   int end_is_call_end;   // 1: pulse still high at fall_hi is discarded (framer.py:102-108); 0: halo error
-  int rec_cap;           // centres per workgroup
+  int rec_cap;           // centres per unit
   int long_cap;
-  unsigned long long* cands;  // [grid][rec_cap]
-  int* blk_count;        // [grid]
-  long long* blk_lastp;  // [grid]
-  unsigned* blk_flags;   // [grid]
+  unsigned long long* cands;  // [units][rec_cap]
+  int* blk_count;        // [units]
+  long long* blk_lastp;  // [units]
+  unsigned* blk_flags;   // [units]
   LongRise* longlist;
   int* long_count;
   unsigned long long* long_lastp;   // biased: centre + 2^62, 0 = none
@@ -271,26 +260,22 @@ __device__ void emit_record(const DetectArgs& a, long long p, unsigned xflags, R
 // into |IQ|^2 floats in LDS AND into the natural-order threshold bitmask words of those samples
 // (span_commit) -- so the fetch of tile k+1 is in flight while tile k is processed, and the threshold
 // masks cost no LDS re-read.  The fast path (whole span inside the buffer) has no per-load branches.
-template <bool C, class A, class B> struct Pick { using type = A; };
-template <class A, class B> struct Pick<false, A, B> { using type = B; };
-
-template <int MODE, int COUNT>
+template <int MODE, int COUNT, int NWAVES = kWaves>
 struct Span {
-  static constexpr bool L8 = (MODE == 0) && kLoad8;           // 8-byte loads, 1 sample per lane
-  static constexpr int PER = L8 ? 1 : (MODE == 0) ? 2 : 4;    // samples per load (complex64: 2; float / int16 IQ: 4)
-  static constexpr int SHARE = COUNT / kWaves;                // samples per wavefront
+  static constexpr int PER = (MODE == 0) ? 2 : 4;             // samples per 16-byte load (complex64: 2; float / int16 IQ: 4)
+  static constexpr int SHARE = COUNT / NWAVES;                // samples per wavefront (NWAVES share the span)
   static constexpr int GROUP = 64 * PER;                      // samples per wave-wide load
   static constexpr int ITER = (SHARE + GROUP - 1) / GROUP;    // (a partial last group only for the head span)
   static constexpr int LANES = (SHARE < GROUP) ? SHARE / PER : 64;   // active lanes when SHARE < GROUP
-  using Q = typename Pick<L8, float2, float4>::type;
+  using Q = float4;
   Q q[ITER];
 };
 
 // Returns false (wave- and block-uniform) when the span is not entirely inside the buffer: the caller
 // then stages it with span_fill_ragged instead (at most one tile per call ends ragged).
-template <int MODE, int COUNT>
-__device__ __forceinline__ bool span_issue(Span<MODE, COUNT>& sp, const DetectArgs& a, long long src, int wave, int lane) {
-  using S = Span<MODE, COUNT>;
+template <int MODE, int COUNT, int NWAVES>
+__device__ __forceinline__ bool span_issue(Span<MODE, COUNT, NWAVES>& sp, const DetectArgs& a, long long src, int wave, int lane) {
+  using S = Span<MODE, COUNT, NWAVES>;
   if (src + COUNT > a.n) return false;
   // scalar base + 32-bit lane offset: one address VGPR for all loads of the span
   const long long wsrc = src + (long long)wave * S::SHARE;
@@ -306,15 +291,14 @@ __device__ __forceinline__ bool span_issue(Span<MODE, COUNT>& sp, const DetectAr
   return true;
 }
 
-// Slow path for the ragged end of the buffer: scalar reads (zeros past the end) straight into LDS, then
-// the mask words by ballot over LDS.  Called by the whole workgroup (contains a barrier).
+// Slow path for the ragged end of the buffer: scalar reads (zeros past the end) straight into LDS, then the
+// mask words by ballot over LDS.  One wavefront stages its own span.
 template <int MODE, int COUNT>
-__device__ __forceinline__ void span_fill_ragged(float* sx, unsigned long long* smask, int dst,
-                                                           const DetectArgs& a, long long src) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < COUNT; i += kThreads) sx[dst + i] = xg<MODE>(a.data, a.n, src + i, a.scale);
-  __syncthreads();
-  for (int w = wave; w < COUNT / 64; w += kWaves) {
+__device__ __forceinline__ void span_fill_ragged_w(float* sx, unsigned long long* smask, int dst,
+                                                   const DetectArgs& a, long long src, int lane) {
+  for (int i = lane; i < COUNT; i += 64) sx[dst + i] = xg<MODE>(a.data, a.n, src + i, a.scale);
+  adsb_wave_sync();
+  for (int w = 0; w < COUNT / 64; ++w) {
     const unsigned long long m = __ballot(sx[dst + 64 * w + lane] >= a.thr);
     if (lane == 0) smask[(dst >> 6) + w] = m;
   }
@@ -323,23 +307,16 @@ __device__ __forceinline__ void span_fill_ragged(float* sx, unsigned long long* 
 // dst = LDS sample index of the span's first sample (multiple of 64).  Every lane of the wavefront
 // must call this (ballots); a wavefront whose share is one 64-sample word (the head span) uses only
 // its low lanes for data and writes one mask word.
-template <int MODE, int COUNT>
-__device__ __forceinline__ void span_commit(const Span<MODE, COUNT>& sp, float* sx, unsigned long long* smask,
+template <int MODE, int COUNT, int NWAVES>
+__device__ __forceinline__ void span_commit(const Span<MODE, COUNT, NWAVES>& sp, float* sx, unsigned long long* smask,
                                             int dst, float thr, float scale, int wave, int lane) {
-  using S = Span<MODE, COUNT>;
+  using S = Span<MODE, COUNT, NWAVES>;
   const int wdst = dst + wave * S::SHARE;
   const bool act = (S::LANES == 64) || lane < S::LANES;
 #pragma unroll
   for (int k = 0; k < S::ITER; ++k) {
     const int g = wdst + k * S::GROUP;                        // first LDS sample of this wave-wide group
-    if constexpr (S::L8) {
-      const float m = mag2f(sp.q[k].x, sp.q[k].y);
-      sx[g + lane] = m;
-      if (kAblate < 3) {
-        const unsigned long long w0 = __ballot(m >= thr);     // one sample per lane: already in natural order
-        if (lane == 0) smask[g >> 6] = w0;
-      }
-    } else if constexpr (MODE == 0) {
+    if constexpr (MODE == 0) {
       float2 m;
       m.x = mag2f(sp.q[k].x, sp.q[k].y);
       m.y = mag2f(sp.q[k].z, sp.q[k].w);
@@ -383,107 +360,104 @@ __device__ __forceinline__ void span_commit(const Span<MODE, COUNT>& sp, float* 
   }
 }
 
-// ---- k_detect: the streaming kernel ----------------------------------------------------------------
-// One workgroup walks a contiguous chunk of the stream tile by tile with a sliding LDS window of
-// kTile + kFwd |IQ|^2 floats plus their threshold bitmask (the forward halo of one tile is the head of the
-// next, so every sample is fetched from HBM once).  Each wavefront stages and owns a quarter of the
-// tile; three barriers per tile.  Matched centres are appended to the workgroup's own slice of `cands`
-// in stream order; ordering across workgroups is by workgroup index (k_scan / k_gather).
+// ---- k_detect: the streaming kernel, one independent stream segment per WAVEFRONT -------------------
+// Each wavefront ("unit" = blockIdx*4 + wave) walks its own contiguous chunk of the stream tile by tile with
+// its own sliding LDS window (kWTile + kFwd |IQ|^2 floats and their threshold mask words: the forward halo
+// of one tile is the head of the next, so every sample is fetched from HBM exactly once), its own rise list
+// and its own output list.  Nothing is shared between the wavefronts of a workgroup: there is no workgroup
+// barrier, and a wavefront that meets a burst does not hold up three others (a first version with four
+// wavefronts sharing a 4096-sample tile and three barriers per tile was 5 % slower).  a.chunk is the chunk of
+// ONE unit (multiple of kWTile); matched centres are appended to the unit's slice of `cands` in stream order;
+// ordering across units is by unit index (k_scan / k_gather).
 template <int MODE>
 __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_x[kWin];
-  __shared__ unsigned long long s_mask[kWords];
-  __shared__ unsigned short s_rise[kWaves][kQuarter / 2];
-  __shared__ int s_nmatch[kWaves], s_wlastp[kWaves], s_wflags[kWaves];
-  __shared__ int s_nrec, s_pred;
-  __shared__ unsigned s_flags;
+  __shared__ __attribute__((aligned(16))) float s_xa[kWaves][kWWin];
+  __shared__ unsigned long long s_maska[kWaves][kWWords];
+  __shared__ unsigned short s_risea[kWaves][kWTile / 2];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = adsb_uniform(tid >> 6);
-  const long long c0 = (long long)blockIdx.x * a.chunk;
+  const int lane = threadIdx.x & 63, wave = adsb_uniform((int)(threadIdx.x >> 6));
+  float* s_x = s_xa[wave];
+  unsigned long long* s_mask = s_maska[wave];
+  unsigned short* s_rise = s_risea[wave];
+  const long long unit = (long long)blockIdx.x * kWaves + wave;
+  const long long c0 = unit * a.chunk;
   long long c1 = c0 + a.chunk;
   if (c1 > a.scan_hi) c1 = a.scan_hi;
   const int half = a.sps >> 1;
   long long lastp_g = kNoIndex;
+  int nrec = 0;                                              // wave-uniform running count of this unit's list
+  unsigned uflags = 0u;
+  int pred = adsb_uniform(above_at<MODE>(a, c0 - 1) ? 1 : 0);
+  unsigned long long* my_cands = a.cands + unit * a.rec_cap;
 
-  if (tid == 0) {
-    s_nrec = 0; s_flags = 0u; s_pred = above_at<MODE>(a, c0 - 1) ? 1 : 0;
-    // virtual rise in the zero history in front of a fresh stream: only possible when 0 >= thr
-    if (blockIdx.x == 0 && a.scan_lo < 0 && (0.0f >= a.thr) && !(a.prev_in0 >= a.thr)) {
-      s_flags |= 1u;
-      if (0 < a.rec_cap) {
-        a.cands[0] = cand_make(a.scan_lo, kPending | kNoMatch);
-        const int li = atomicAdd(a.long_count, 1);
-        if (li < a.long_cap) { LongRise e; e.rise = a.scan_lo; e.blk = 0; e.slot = 0; a.longlist[li] = e; }
-      }
-      s_nrec = 1;
+  // virtual rise in the zero history in front of a fresh stream: only possible when 0 >= thr
+  if (unit == 0 && a.scan_lo < 0 && (0.0f >= a.thr) && !(a.prev_in0 >= a.thr)) {
+    uflags |= 1u;
+    if (lane == 0 && 0 < a.rec_cap) {
+      my_cands[0] = cand_make(a.scan_lo, kPending | kNoMatch);
+      const int li = atomicAdd(a.long_count, 1);
+      if (li < a.long_cap) { LongRise e; e.rise = a.scan_lo; e.blk = 0; e.slot = 0; a.longlist[li] = e; }
     }
+    nrec = 1;
   }
 
-  // prologue: head of the first tile straight into LDS (with its mask words), first body into registers
-  Span<MODE, kTile> body;
+  Span<MODE, kWTile, 1> body;
   bool body_ok = true;
   if (c0 < c1) {
-    Span<MODE, kFwd> head;
-    const bool head_ok = span_issue<MODE, kFwd>(head, a, c0, wave, lane);
-    body_ok = span_issue<MODE, kTile>(body, a, c0 + kFwd, wave, lane);
-    if (head_ok) span_commit<MODE, kFwd>(head, s_x, s_mask, 0, a.thr, a.scale, wave, lane);
-    else span_fill_ragged<MODE, kFwd>(s_x, s_mask, 0, a, c0);
+    Span<MODE, kFwd, 1> head;
+    const bool head_ok = span_issue(head, a, c0, 0, lane);
+    body_ok = span_issue(body, a, c0 + kFwd, 0, lane);
+    if (head_ok) span_commit(head, s_x, s_mask, 0, a.thr, a.scale, 0, lane);
+    else span_fill_ragged_w<MODE, kFwd>(s_x, s_mask, 0, a, c0, lane);
   }
 
-  for (long long t0 = c0; t0 < c1; t0 += kTile) {
-    // -- A: window [t0, t0+kWin).  s_x[0..kFwd) and mask words 0..3 already hold the head; commit the body
-    //       (floats + mask words 4..67), then start fetching the next body so it is in flight below
-    if (!body_ok) span_fill_ragged<MODE, kTile>(s_x, s_mask, kFwd, a, t0 + kFwd);
-    else if (kAblate < 4) span_commit<MODE, kTile>(body, s_x, s_mask, kFwd, a.thr, a.scale, wave, lane);
-    else { float acc = 0.0f; for (int k = 0; k < Span<MODE, kTile>::ITER; ++k) acc += body.q[k].x + body.q[k].y; if (acc == 123.456f) s_x[tid] = acc; }
-    if (!kLateIssue && t0 + kTile < c1) body_ok = span_issue<MODE, kTile>(body, a, t0 + kTile + kFwd, wave, lane);
-    __syncthreads();
+  for (long long t0 = c0; t0 < c1; t0 += kWTile) {
+    // -- A: commit this tile's body (floats + mask words 4..19), start fetching the next one
+    if (!body_ok) span_fill_ragged_w<MODE, kWTile>(s_x, s_mask, kFwd, a, t0 + kFwd, lane);
+    else span_commit(body, s_x, s_mask, kFwd, a.thr, a.scale, 0, lane);
+    if (t0 + kWTile < c1) body_ok = span_issue(body, a, t0 + kWTile + kFwd, 0, lane);
+    adsb_wave_sync();
 
-    // -- B: every wavefront handles the rises of its own 16 mask words, no cross-wave sync inside
+    // -- B.1 rises / falls by mask algebra (framer.py:91-93); lanes 0..15 own one word each
+    const int word = lane & 15;
+    const unsigned long long M = (kAblate >= 3) ? 0ull : s_mask[word];
+    const unsigned long long pb = (kAblate >= 3) ? 0ull : (word > 0) ? (s_mask[word - 1] >> 63) : (unsigned long long)pred;
+    const unsigned long long sh = (M << 1) | pb;
+    const long long wbase = t0 + 64ll * word;
+    const unsigned long long own = (lane < 16) ? bit_range(a.scan_lo - wbase, a.scan_hi - wbase) : 0ull;
+    unsigned long long R = M & ~sh & own;
+    const unsigned long long Fm = ~M & sh & own;
+    const unsigned long long anyr = (kAblate >= 2) ? 0ull : __ballot(R != 0ull), anyf = __ballot(Fm != 0ull);
+    uflags |= (anyr ? 1u : 0u) | (anyf ? 2u : 0u);
     int nm = 0;
-    if (kAblate < 3) {
-      // B.1 rises / falls by mask algebra (framer.py:91-93); lanes 0..15 own one word each
-      const int word = wave * kQWords + (lane & 15);
-      const unsigned long long M = s_mask[word];
-      const unsigned long long pb = (word > 0) ? (s_mask[word - 1] >> 63) : (unsigned long long)s_pred;
-      const unsigned long long sh = (M << 1) | pb;
-      const long long wbase = t0 + 64ll * word;
-      const unsigned long long own = (lane < 16) ? bit_range(a.scan_lo - wbase, a.scan_hi - wbase) : 0ull;
-      unsigned long long R = M & ~sh & own;
-      const unsigned long long Fm = ~M & sh & own;
-      const unsigned long long anyr = __ballot(R != 0ull), anyf = __ballot(Fm != 0ull);
-      if (lane == 0) { s_wflags[wave] = (anyr ? 1 : 0) | (anyf ? 2 : 0); s_wlastp[wave] = -1; }
-      // exclusive prefix of the 16 word counts with scalar lane reads (no LDS round trips)
-      const int cnt = __popcll(R);
-      int pos = 0, nr = 0;
-      if (anyr) {                                          // wave-uniform: quiet stretches skip everything below
+    if (anyr) {                                            // wave-uniform: quiet stretches skip everything below
+      // ordered rise list: word by word (wave-uniform loop over the 16 words, empty ones skipped), lane l
+      // takes bit l of the word and its slot from the prefix popcount -- no per-lane serial bit loop
+      const int rlo = (int)(unsigned)R, rhi = (int)(unsigned)(R >> 32);
+      int nr = 0;
 #pragma unroll
-        for (int j = 0; j < kQWords; ++j) {
-          const int cj = adsb_readlane(cnt, j);
-          if (lane > j) pos += cj;
-          nr += cj;
-        }
-        while (R) {
-          const int b = __builtin_ctzll(R);
-          R &= R - 1ull;
-          s_rise[wave][pos++] = (unsigned short)(64 * word + b);
+      for (int j = 0; j < kWOwn; ++j) {
+        const unsigned long long Rj = (unsigned long long)(unsigned)adsb_readlane(rlo, j) |
+                                      ((unsigned long long)(unsigned)adsb_readlane(rhi, j) << 32);
+        if (Rj) {
+          if ((Rj >> lane) & 1ull) s_rise[nr + lanes_below(Rj, lane)] = (unsigned short)(64 * j + lane);
+          nr += __popcll(Rj);
         }
       }
       adsb_wave_sync();
 
-      // B.2 per rise: fall, centre, 16-chip test (framer.py:113,137-147)
+      // -- B.2 per rise: fall, centre, 16-chip test (framer.py:113,137-147)
       int lp = -1, lp2 = -1, hflag = 0;
-      const int nre = (kAblate >= 2) ? 0 : nr;
-      for (int i = lane; i < nre; i += 64) {
-        const int r = s_rise[wave][i];
+      for (int i = lane; i < nr; i += 64) {
+        const int r = s_rise[i];
         int w = r >> 6;
         const int b = r & 63;
         unsigned long long inv = ~s_mask[w];
         inv = (b == 63) ? 0ull : (inv & (~0ull << (b + 1)));
-        while (inv == 0ull && ++w < kWords) inv = ~s_mask[w];
+        while (inv == 0ull && ++w < kWWords) inv = ~s_mask[w];
         unsigned short res = 0;
         if (inv == 0ull) {
-          if (t0 + kWin < a.fall_hi) res = 0xFFFFu;        // pulse longer than the window: k_longrun
+          if (t0 + kWWin < a.fall_hi) res = 0xFFFFu;       // pulse longer than the window: k_longrun
           else if (!a.end_is_call_end) hflag = 4;
         } else {
           const int f = w * 64 + __builtin_ctzll(inv);
@@ -493,15 +467,15 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
             else if (i == nr - 2) lp2 = p;                 // a tile can be left without a fall
             const float hp = __fmul_rn(s_x[p], 0.5f);      // in0[pulse_idx]/2, exact
             unsigned chips = 0;
-            if (p + 15 * half < kWin) {                    // all 16 taps inside the LDS window
+            if (p + 15 * half < kWWin) {                   // all 16 taps inside the LDS window
               const float* tp = s_x + p;
-#pragma unroll 4
+#pragma unroll ADSB_TAP_UNROLL
               for (int k = 0; k < 16; ++k) chips |= (tp[k * half] > hp ? 1u : 0u) << k;
             } else {                                       // rare: taps past the window come from global memory
 #pragma unroll 1
               for (int k = 0; k < 16; ++k) {
                 const int idx = p + k * half;
-                const float v = (idx < kWin) ? s_x[idx] : xg<MODE>(a.data, a.n, t0 + idx, a.scale);
+                const float v = (idx < kWWin) ? s_x[idx] : xg<MODE>(a.data, a.n, t0 + idx, a.scale);
                 chips |= (v > hp ? 1u : 0u) << k;
               }
             }
@@ -510,93 +484,71 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
             hflag = 4;
           }
         }
-        s_rise[wave][i] = res;
+        s_rise[i] = res;
       }
-      // last paired centre of this wavefront's quarter and halo flag -> one LDS word per wavefront
-      if (nre > 0) {
+      {
         const unsigned long long m1 = __ballot(lp >= 0), m2 = __ballot(lp2 >= 0), mh = __ballot(hflag != 0);
         const int v1 = __shfl(lp, m1 ? __builtin_ctzll(m1) : 0);
         const int v2 = __shfl(lp2, m2 ? __builtin_ctzll(m2) : 0);
-        if (lane == 0) {
-          s_wlastp[wave] = m1 ? v1 : (m2 ? v2 : -1);
-          if (mh) s_wflags[wave] |= 4;
-        }
-        adsb_wave_sync();
+        const int wl = m1 ? v1 : (m2 ? v2 : -1);
+        if (wl >= 0) lastp_g = t0 + wl;
+        if (mh) uflags |= 4u;
       }
+      adsb_wave_sync();
 
-      // B.3 ordered in-place compaction of this wavefront's matched centres
-      for (int base = 0; base < nre; base += 64) {
+      // -- B.3 ordered in-place compaction of the matched centres
+      for (int base = 0; base < nr; base += 64) {
         const int i = base + lane;
-        const unsigned short e = (i < nre) ? s_rise[wave][i] : (unsigned short)0;
+        const unsigned short e = (i < nr) ? s_rise[i] : (unsigned short)0;
         const unsigned long long mb = __ballot(e != 0);
-        if (e) s_rise[wave][nm + lanes_below(mb, lane)] = e;
+        if (e) s_rise[nm + lanes_below(mb, lane)] = e;
         nm += __popcll(mb);
       }
-      if (lane == 0) s_nmatch[wave] = nm;
-    } else {
-      if (lane == 0) { s_nmatch[wave] = 0; s_wlastp[wave] = -1; s_wflags[wave] = 0; }
-    }
-    __syncthreads();
+      adsb_wave_sync();
 
-    // -- C: append the matched centres (wave order == stream order) to this workgroup's list
-    int pre = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
-      const int c = s_nmatch[w];
-      if (w < wave) pre += c;
-      tot += c;
-    }
-    const int rec_base = s_nrec;
-    if (kAblate < 1) {
+      // -- C: append to this unit's list (stream order by construction)
       for (int i = lane; i < nm; i += 64) {
-        const unsigned short e = s_rise[wave][i];
-        const int slot = rec_base + pre + i;
+        const unsigned short e = s_rise[i];
+        const int slot = nrec + i;
         if (slot < a.rec_cap) {
-          unsigned long long* out = a.cands + (long long)blockIdx.x * a.rec_cap + slot;
           if (e == 0xFFFFu) {
             // the long pulse is the last rise of its tile: recover its index from the masks
             long long rg = kNoIndex;
-            for (int w2 = kOwnWords - 1; w2 >= 0 && rg == kNoIndex; --w2) {
-              const unsigned long long M = s_mask[w2];
-              const unsigned long long pb = (w2 > 0) ? (s_mask[w2 - 1] >> 63) : (unsigned long long)s_pred;
+            for (int w2 = kWOwn - 1; w2 >= 0 && rg == kNoIndex; --w2) {
+              const unsigned long long M2 = s_mask[w2];
+              const unsigned long long pb2 = (w2 > 0) ? (s_mask[w2 - 1] >> 63) : (unsigned long long)pred;
               const long long wb = t0 + 64ll * w2;
-              const unsigned long long R = M & ~((M << 1) | pb) & bit_range(a.scan_lo - wb, a.scan_hi - wb);
-              if (R) rg = wb + (63 - __builtin_clzll(R));
+              const unsigned long long R2 = M2 & ~((M2 << 1) | pb2) & bit_range(a.scan_lo - wb, a.scan_hi - wb);
+              if (R2) rg = wb + (63 - __builtin_clzll(R2));
             }
-            *out = cand_make(rg, kPending | kNoMatch);
+            my_cands[slot] = cand_make(rg, kPending | kNoMatch);
             const int li = atomicAdd(a.long_count, 1);
-            if (li < a.long_cap) { LongRise le; le.rise = rg; le.blk = (int)blockIdx.x; le.slot = slot; a.longlist[li] = le; }
+            if (li < a.long_cap) { LongRise le; le.rise = rg; le.blk = (int)unit; le.slot = slot; a.longlist[li] = le; }
           } else {
-            *out = cand_make(t0 + (long long)(e & 0x7FFFu), 0u);
+            my_cands[slot] = cand_make(t0 + (long long)(e & 0x7FFFu), 0u);
           }
         }
       }
+      nrec += nm;
     }
+
     // what the next tile inherits: the forward halo (floats + mask words) and the last threshold bit
-    const float keep = s_x[kTile + tid];
-    const unsigned long long keepm = (tid < kHeadWords) ? s_mask[kOwnWords + tid] : 0ull;
-    int wl = -1, keepp = 0; unsigned wf = 0;
-    if (tid == 0) {
-      keepp = (int)(s_mask[kOwnWords - 1] >> 63);
+    float keep[kFwd / 64];
 #pragma unroll
-      for (int w = 0; w < kWaves; ++w) { if (s_wlastp[w] >= 0) wl = s_wlastp[w]; wf |= (unsigned)s_wflags[w]; }
-    }
-    if (kLateIssue && t0 + kTile < c1) body_ok = span_issue<MODE, kTile>(body, a, t0 + kTile + kFwd, wave, lane);
-    __syncthreads();
-    s_x[tid] = keep;
-    if (tid < kHeadWords) s_mask[tid] = keepm;
-    if (tid == 0) {
-      s_pred = keepp;
-      s_nrec = rec_base + ((kAblate < 1) ? tot : 0);
-      s_flags |= wf;
-      if (wl >= 0) lastp_g = t0 + wl;
-    }
+    for (int j = 0; j < kFwd / 64; ++j) keep[j] = s_x[kWTile + lane + 64 * j];
+    const unsigned long long keepm = (lane < kHeadWords) ? s_mask[kWOwn + lane] : 0ull;
+    const int keepp = adsb_uniform((int)(s_mask[kWOwn - 1] >> 63));
+    adsb_wave_sync();
+#pragma unroll
+    for (int j = 0; j < kFwd / 64; ++j) s_x[lane + 64 * j] = keep[j];
+    if (lane < kHeadWords) s_mask[lane] = keepm;
+    pred = keepp;
+    // (the next iteration's commit writes s_x[kFwd..] and mask words >= 4; its wave_sync orders all of it)
   }
-  __syncthreads();
-  if (tid == 0) {
-    a.blk_count[blockIdx.x] = s_nrec;
-    a.blk_lastp[blockIdx.x] = lastp_g;
-    a.blk_flags[blockIdx.x] = s_flags;
+  if (lane == 0) {
+    a.blk_count[unit] = nrec;
+    a.blk_lastp[unit] = lastp_g;
+    a.blk_flags[unit] = uflags;
   }
 }
 

@@ -59,7 +59,7 @@ struct Slot {
   bool ev1_valid = false;
   Plan plan{};
   DetectArgs args{};
-  int grid = 0, rec_cap = 0;
+  int grid = 0, nlists = 0, rec_cap = 0;
   long long tot = 0, ntiles = 0, chunk = 0, span = 0;
   int32_t nres = 0;
 };
@@ -133,6 +133,13 @@ void launch_detect(adsb_ctx* c, const DetectArgs& a, int grid) {
   hipLaunchKernelGGL((k_detect<MODE>), dim3(grid), dim3(kThreads), dyn, c->stream, a);
 }
 template <int MODE>
+int detect_occupancy() {
+  int nb = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_detect<MODE>, kThreads, 0);
+  if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return nb;
+}
+template <int MODE>
 void launch_burst(adsb_ctx* c, hipStream_t st, const DetectArgs& a, const unsigned long long* kept, const Summary* sum,
                   Rec* out, int cap) {
   hipLaunchKernelGGL((k_burst<MODE>), dim3(c->n_cu * 8), dim3(kThreads), 0, st, a, kept, sum, out, cap);
@@ -158,13 +165,13 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   // no-op unless k_detect listed pulses longer than its LDS window
   if (pl.mode == 0) launch_longrun<0>(ts, a); else if (pl.mode == 1) launch_longrun<1>(ts, a); else launch_longrun<2>(ts, a);
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(kThreads), 0, ts, (const int*)a.blk_count,
-                     (const long long*)a.blk_lastp, (const unsigned*)a.blk_flags, s.grid, s.rec_cap,
+                     (const long long*)a.blk_lastp, (const unsigned*)a.blk_flags, s.nlists, s.rec_cap,
                      (const int*)a.long_count, (const unsigned long long*)a.long_lastp, (int*)s.d_blk_off.p, &misc->sum);
-  const int gg = s.grid < 1024 ? s.grid : 1024;
+  const int gg = s.nlists < 1024 ? s.nlists : 1024;
   unsigned long long* sorted = (unsigned long long*)s.d_sorted.p;
   unsigned long long* kept = (unsigned long long*)s.d_kept.p;
   hipLaunchKernelGGL(k_gather, dim3(gg), dim3(kThreads), 0, ts, (const unsigned long long*)a.cands,
-                     (const int*)a.blk_count, (const int*)s.d_blk_off.p, s.grid, s.rec_cap, sorted);
+                     (const int*)a.blk_count, (const int*)s.d_blk_off.p, s.nlists, s.rec_cap, sorted);
   const int ag = 512;
   unsigned fmask = 0u, fwant = 0u;
   if (pl.gate) {
@@ -190,18 +197,23 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   HIPCHK(c, hipSetDevice(c->device));
   s.plan = pl;
   s.span = pl.scan_hi > 0 ? pl.scan_hi : 0;
-  long long ntiles = (s.span + kTile - 1) / kTile;
+  // A "unit" (one wavefront) walks one contiguous chunk and owns one output list.  Exactly one resident round
+  // of workgroups: a partial second round costs ~20 % (tail effect).
+  const int upb = kWaves;                                  // units per workgroup
+  const int tile = kWTile;
+  long long ntiles = (s.span + tile - 1) / tile;
   if (ntiles < 1) ntiles = 1;
-  // exactly one resident round of workgroups: a partial second round costs ~20 % (tail effect)
   static const int bpc_env = getenv("ADSB_DEBUG_BPC") ? atoi(getenv("ADSB_DEBUG_BPC")) : 0;
-  const long long gmax = (long long)c->n_cu * (bpc_env > 0 ? bpc_env : c->bpc[pl.mode]);
-  int grid = (int)(ntiles < gmax ? ntiles : gmax);
-  const long long tiles_per = (ntiles + grid - 1) / grid;
-  grid = (int)((ntiles + tiles_per - 1) / tiles_per);
-  const long long chunk = tiles_per * kTile;
+  const long long umax = (long long)c->n_cu * (bpc_env > 0 ? bpc_env : c->bpc[pl.mode]) * upb;
+  long long units = ntiles < umax ? ntiles : umax;
+  const long long tiles_per = (ntiles + units - 1) / units;
+  units = (ntiles + tiles_per - 1) / tiles_per;
+  const long long chunk = tiles_per * tile;
+  const int grid = (int)((units + upb - 1) / upb);
+  const int nlists = grid * upb;                           // units past `units` own nothing and report empty lists
   long long rc = (chunk / 256 + 64) << c->rec_cap_shift;
   if (rc > chunk / 2 + 8) rc = chunk / 2 + 8;   // there can never be more rises than that
-  s.grid = grid; s.rec_cap = (int)rc; s.tot = (long long)grid * rc; s.ntiles = ntiles; s.chunk = chunk;
+  s.grid = grid; s.nlists = nlists; s.rec_cap = (int)rc; s.tot = (long long)nlists * rc; s.ntiles = ntiles; s.chunk = chunk;
   const long long long_cap = ntiles + 1;        // at most one long pulse per tile, plus the virtual rise
   int r;
   if ((r = ensure(c, s.d_cands, (size_t)s.tot * 8))) return r;
@@ -209,10 +221,10 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   if ((r = ensure(c, s.d_kept, (size_t)s.tot * 8))) return r;
   if ((r = ensure(c, s.d_out, (size_t)s.tot * sizeof(Rec)))) return r;
   if ((r = ensure(c, s.d_seg, (size_t)(s.tot / kThreads + 2) * sizeof(int)))) return r;
-  if ((r = ensure(c, s.d_blk_count, (size_t)grid * sizeof(int)))) return r;
-  if ((r = ensure(c, s.d_blk_lastp, (size_t)grid * sizeof(long long)))) return r;
-  if ((r = ensure(c, s.d_blk_flags, (size_t)grid * sizeof(unsigned)))) return r;
-  if ((r = ensure(c, s.d_blk_off, (size_t)grid * sizeof(int)))) return r;
+  if ((r = ensure(c, s.d_blk_count, (size_t)nlists * sizeof(int)))) return r;
+  if ((r = ensure(c, s.d_blk_lastp, (size_t)nlists * sizeof(long long)))) return r;
+  if ((r = ensure(c, s.d_blk_flags, (size_t)nlists * sizeof(unsigned)))) return r;
+  if ((r = ensure(c, s.d_blk_off, (size_t)nlists * sizeof(int)))) return r;
   if ((r = ensure(c, s.d_long, (size_t)long_cap * sizeof(LongRise)))) return r;
   if (!s.d_misc.p) {
     if ((r = ensure(c, s.d_misc, sizeof(Misc)))) return r;
@@ -376,10 +388,10 @@ int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
   {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_detect<0>, kThreads, 0) == hipSuccess && nb > 0) c->bpc[0] = nb;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_detect<1>, kThreads, 0) == hipSuccess && nb > 0) c->bpc[1] = nb;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_detect<2>, kThreads, 0) == hipSuccess && nb > 0) c->bpc[2] = nb;
+    int nb;
+    if ((nb = detect_occupancy<0>()) > 0) c->bpc[0] = nb;
+    if ((nb = detect_occupancy<1>()) > 0) c->bpc[1] = nb;
+    if ((nb = detect_occupancy<2>()) > 0) c->bpc[2] = nb;
   }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return -EIO; }
   c->own_stream = true;

@@ -24,15 +24,21 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
             long long fall_hi, long long dem_hi, long long origin, float thr, float prev_in0, int sps,
             int end_is_call_end, long long prev_eob_stream, int gate, int head_n, int grid_max, int rec_cap_in, float scale,
             unsigned long long* out_recs /* 4 words each */, int out_cap, SimOut* so) {
+  // same unit geometry as adsb_hip.hip: enqueue()  (grid_max = resident workgroups available)
   const long long span = scan_hi > 0 ? scan_hi : 0;
-  long long ntiles = (span + kTile - 1) / kTile;
+  const int upb = kWaves;
+  const int tile = kWTile;
+  long long ntiles = (span + tile - 1) / tile;
   if (ntiles < 1) ntiles = 1;
-  int grid = (int)(ntiles < grid_max ? ntiles : grid_max);
-  const long long tiles_per = (ntiles + grid - 1) / grid;
-  grid = (int)((ntiles + tiles_per - 1) / tiles_per);
-  const long long chunk = tiles_per * kTile;
+  const long long umax = (long long)grid_max * upb;
+  long long units = ntiles < umax ? ntiles : umax;
+  const long long tiles_per = (ntiles + units - 1) / units;
+  units = (ntiles + tiles_per - 1) / tiles_per;
+  const long long chunk = tiles_per * tile;
+  const int grid = (int)((units + upb - 1) / upb);
+  const int nlists = grid * upb;
   const int rec_cap = rec_cap_in > 0 ? rec_cap_in : (int)(chunk / 2 + 8);
-  const long long tot = (long long)grid * rec_cap;
+  const long long tot = (long long)nlists * rec_cap;
 
   // data must be 16-byte aligned like a device allocation
   const size_t nfl = (size_t)n * (mode == 0 ? 2 : 1);   // 4-byte units: complex64 = 2, float / int16 IQ = 1
@@ -41,9 +47,9 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
 
   std::vector<unsigned long long> cands(tot), sorted(tot), kept(tot);
   std::vector<Rec> outv(tot);
-  std::vector<int> blk_count(grid), blk_off(grid), seg(tot / kThreads + 2);
-  std::vector<long long> blk_lastp(grid);
-  std::vector<unsigned> blk_flags(grid);
+  std::vector<int> blk_count(nlists), blk_off(nlists), seg(tot / kThreads + 2);
+  std::vector<long long> blk_lastp(nlists);
+  std::vector<unsigned> blk_flags(nlists);
   std::vector<LongRise> longlist(ntiles + 1);
   int long_count = 0;
   unsigned long long long_lastp = 0;
@@ -66,10 +72,10 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   else hipsim::launch(k_longrun<2>, 3, kThreads, a);
   {
     hipsim::launch(k_scan, 1, kThreads, (const int*)blk_count.data(), (const long long*)blk_lastp.data(),
-                   (const unsigned*)blk_flags.data(), grid, rec_cap, (const int*)&long_count,
+                   (const unsigned*)blk_flags.data(), nlists, rec_cap, (const int*)&long_count,
                    (const unsigned long long*)&long_lastp, blk_off.data(), &sum);
-    hipsim::launch(k_gather, grid < 8 ? grid : 8, kThreads, (const unsigned long long*)cands.data(),
-                   (const int*)blk_count.data(), (const int*)blk_off.data(), grid, rec_cap, sorted.data());
+    hipsim::launch(k_gather, nlists < 8 ? nlists : 8, kThreads, (const unsigned long long*)cands.data(),
+                   (const int*)blk_count.data(), (const int*)blk_off.data(), nlists, rec_cap, sorted.data());
     unsigned fmask = 0u, fwant = 0u;
     if (gate) {
       hipsim::launch(k_resolve, 3, kThreads, sorted.data(), (const Summary*)&sum, (long long)63 * sps,

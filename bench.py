@@ -124,20 +124,21 @@ def main():
         iq = gen_stream_blocks(plan["hi"] - plan["lo"], plan["lo"], fs, args.bursts, args.seed, dev)
     torch.cuda.synchronize()
 
-    pending = []          # tickets of submitted, not yet collected passes (N=1: two-deep pipeline)
+    DEPTH = _native.MAX_IN_FLIGHT
+    pending = []          # tickets of submitted, not yet collected passes (pipeline of DEPTH passes)
 
     def step():
         if n_gpus == 1:
             # submit pass i+1 before collecting pass i: the PCIe copy and host work of one pass overlap the
             # kernels of the next; every pass is collected inside the timed region (drain() below)
             pending.append(fe.submit_iq16_tensor(iq, 0) if sc16 else fe.submit_iq_tensor(iq, 0))
-            if len(pending) == 2:
+            if len(pending) == DEPTH:
                 return fe.wait(pending.pop(0), fetch=False)
             return 0
         # N>1: same two-deep pipeline; the host stitch of pass i (two tiny all_gathers) overlaps the GPU pass i+1
         pending.append(fe.submit_shard_tensor(iq, plan["lo"], plan["own_lo"], plan["own_hi"], stream_len,
                                               head_cands=sharding.HEAD_CANDS))
-        if len(pending) == 2:
+        if len(pending) == DEPTH:
             return collect_shard(pending.pop(0))
         return 0
 
@@ -233,7 +234,7 @@ def main():
                             % (fs / 1e6, "int16" if sc16 else "complex64", args.bursts, args.threshold, args.log2n),
                 "fs": fs, "samples_per_gpu_per_step": n_own, "bursts_per_step_rank0": int(n_bursts),
                 "sharding": "none" if n_gpus == 1 else "%d overlapped time shards, host stitch" % n_gpus,
-                "pipeline": "2 passes in flight (submit/wait)",
+                "pipeline": "%d passes in flight (submit/wait)" % DEPTH,
                 "detect_gap_ms_avg": round(st["detect_gap_ms"] / max(1, st["detect_gaps"]), 4),
                 "detect_grid": int(st["detect_grid"]), "retries": int(st["retries"]), "longrun_calls": int(st["longrun_calls"]),
             },

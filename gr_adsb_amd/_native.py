@@ -17,6 +17,7 @@ assert BURST_DTYPE.itemsize == 32
 FLAG_TIMING = 1
 BURST_DEMOD = 1
 BURST_KEPT = 2
+MAX_IN_FLIGHT = 3
 
 EXPORTS = [
     "adsb_abi_version", "adsb_create", "adsb_destroy", "adsb_set_threshold", "adsb_set_stream", "adsb_reset",

@@ -81,7 +81,7 @@ struct adsb_ctx {
   int bpc[3] = {4, 4, 4};  // resident k_detect workgroups per CU (occupancy query), per input mode
   float scale16 = 1.0f / 32768.0f;  // int16 IQ component -> float32 multiplier (adsb_set_iq16_scale)
   FramerState st;       // framer.py:54,57
-  Slot slot[2];
+  Slot slot[ADSB_MAX_IN_FLIGHT];
   int next_slot = 0;
   int last_slot = 0;
   DevBuf d_in, d_tags, d_bits, d_ok, d_ratio;
@@ -247,6 +247,7 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   c->stats.detect_grid = (uint64_t)grid; c->stats.blocks_per_cu = (uint64_t)c->bpc[pl.mode];
   c->stats.calls++;
   s.busy = true;
+  s.ev1_valid = timing;
   return enqueue_tail(c, s);
 }
 
@@ -264,14 +265,16 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
       c->stats.detect_launches++;
       c->stats.detect_ms += ms;
       // idle time on the compute stream between the previous pass's k_detect and this one (pipelined use)
-      Slot& prev = c->slot[(&s == &c->slot[0]) ? 1 : 0];
-      if (prev.ev1_valid) {
+      // idle time on the compute stream between this pass's k_detect and the NEXT pass's (already queued in
+      // pipelined use; its events are valid if that pass has been collected or is complete -- best effort)
+      const int me = (int)(&s - c->slot);
+      Slot& nxt = c->slot[(me + 1) % ADSB_MAX_IN_FLIGHT];
+      if (nxt.busy && nxt.ev1_valid) {
         float gap = 0;
-        if (hipEventElapsedTime(&gap, prev.ev1, s.ev0) == hipSuccess && gap >= 0 && gap < 100.0f) {
+        if (hipEventElapsedTime(&gap, s.ev1, nxt.ev0) == hipSuccess && gap >= 0 && gap < 100.0f) {
           c->stats.detect_gap_ms += gap; c->stats.detect_gaps++;
         } else (void)hipGetLastError();
       }
-      s.ev1_valid = true;
       c->stats.detect_samples += (uint64_t)s.span;
       c->stats.detect_bytes += (uint64_t)s.span * (s.plan.mode == 0 ? 8u : 4u);
     }
@@ -305,7 +308,7 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
 
 // Synchronous form used by every blocking entry point.
 int run_pipeline(adsb_ctx* c, const Plan& pl, Summary* sum, int32_t* n_res) {
-  if (c->slot[0].busy || c->slot[1].busy) return fail(c, -EBUSY, "a submitted call is still pending (adsb_wait first)");
+  for (const Slot& sl : c->slot) if (sl.busy) return fail(c, -EBUSY, "a submitted call is still pending (adsb_wait first)");
   Slot& s = c->slot[0];
   c->last_slot = 0;
   int r = enqueue(c, s, pl);
@@ -442,7 +445,7 @@ int adsb_set_threshold(adsb_ctx* c, float threshold) {
 
 int adsb_set_stream(adsb_ctx* c, void* hip_stream) {
   if (!c) return -EINVAL;
-  if (c->slot[0].busy || c->slot[1].busy) return fail(c, -EBUSY, "calls pending");
+  for (const Slot& sl : c->slot) if (sl.busy) return fail(c, -EBUSY, "calls pending");
   if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
   c->stream = (hipStream_t)hip_stream;
   c->own_stream = false;
@@ -515,13 +518,13 @@ static int submit_canonical(adsb_ctx* c, int mode, const void* d_data, int64_t n
   if (!c || n < 1 || !ticket) return -EINVAL;
   if (((uintptr_t)d_data & 15u) != 0) return fail(c, -EINVAL, "device pointer must be 16-byte aligned");
   Slot& s = c->slot[c->next_slot];
-  if (s.busy) return fail(c, -EBUSY, "both pipeline slots are in flight (adsb_wait first)");
+  if (s.busy) return fail(c, -EBUSY, "every pipeline slot is in flight (adsb_wait first)");
   Plan pl = plan_canonical(mode, d_data, n, abs_offset, c->sps);
   int r = enqueue(c, s, pl);
   if (r) { s.busy = false; return r; }
   s.is_shard = false;
   *ticket = c->next_slot;
-  c->next_slot ^= 1;
+  c->next_slot = (c->next_slot + 1) % ADSB_MAX_IN_FLIGHT;
   return 0;
 }
 
@@ -538,7 +541,7 @@ int adsb_submit_mag2_device(adsb_ctx* c, const void* d_mag2, int64_t n, int64_t 
 }
 
 int adsb_wait(adsb_ctx* c, int32_t ticket, adsb_burst* out, int32_t cap, int32_t* n_out) {
-  if (!c || ticket < 0 || ticket > 1) return -EINVAL;
+  if (!c || ticket < 0 || ticket >= ADSB_MAX_IN_FLIGHT) return -EINVAL;
   Slot& s = c->slot[ticket];
   if (!s.busy) return fail(c, -EINVAL, "no call pending on this ticket");
   Summary sum;
@@ -662,12 +665,12 @@ int adsb_submit_shard_device(adsb_ctx* c, int fmt, const void* d_data, int64_t n
   int rc = shard_plan_checked(c, fmt, d_data, n, origin, own_lo, own_hi, stream_len, head_cands, &pl);
   if (rc) return rc;
   Slot& s = c->slot[c->next_slot];
-  if (s.busy) return fail(c, -EBUSY, "both pipeline slots are in flight (adsb_wait first)");
+  if (s.busy) return fail(c, -EBUSY, "every pipeline slot is in flight (adsb_wait first)");
   rc = enqueue(c, s, pl);
   if (rc) { s.busy = false; return rc; }
   s.is_shard = true;
   *ticket = c->next_slot;
-  c->next_slot ^= 1;
+  c->next_slot = (c->next_slot + 1) % ADSB_MAX_IN_FLIGHT;
   return 0;
 }
 

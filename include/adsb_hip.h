@@ -32,6 +32,7 @@ extern "C" {
 #endif
 
 #define ADSB_ABI_VERSION 1
+#define ADSB_MAX_IN_FLIGHT 3 /* adsb_submit_* calls that may be pending at once */
 
 /* adsb_create flags */
 #define ADSB_FLAG_TIMING 1u /* bracket the detect kernel with HIP events (adsb_get_stats) */
@@ -110,12 +111,13 @@ int adsb_process_iq16_device(adsb_ctx* ctx, const void* d_iq16, int64_t n, int64
                              adsb_burst* out, int32_t cap, int32_t* n_out);
 int adsb_last_result(adsb_ctx* ctx, const adsb_burst** bursts, int32_t* n);
 
-/* Two-deep asynchronous form of adsb_process_*_device: submit queues the whole device pipeline on the
- * context's compute stream and returns a ticket (0 or 1) at once; adsb_wait blocks for that call, copies
- * its bursts to pinned host memory on a second stream and delivers them like adsb_process_*.  With call
- * i+1 submitted before waiting for call i the PCIe copy and all host work of call i overlap the kernels of
- * call i+1.  The input buffer must stay valid and unchanged until adsb_wait returns.  At most two calls
- * in flight (-EBUSY otherwise); results must be collected in submission order. */
+/* Asynchronous form of adsb_process_*_device: submit queues the whole device pipeline on the context's
+ * streams and returns a ticket (0 .. ADSB_MAX_IN_FLIGHT-1) at once; adsb_wait blocks for that call, copies
+ * its bursts to pinned host memory on a copy stream and delivers them like adsb_process_*.  With later
+ * calls submitted before waiting for call i, the streaming kernel of call i+1 runs back to back with that
+ * of call i while call i's tail kernels, its PCIe copy and all host work proceed beside it.  The input
+ * buffer must stay valid and unchanged until adsb_wait returns.  At most ADSB_MAX_IN_FLIGHT calls pending
+ * (-EBUSY otherwise); results must be collected in submission order. */
 int adsb_submit_iq_device(adsb_ctx* ctx, const void* d_iq, int64_t n, int64_t abs_offset, int32_t* ticket);
 int adsb_submit_mag2_device(adsb_ctx* ctx, const void* d_mag2, int64_t n, int64_t abs_offset, int32_t* ticket);
 int adsb_submit_iq16_device(adsb_ctx* ctx, const void* d_iq16, int64_t n, int64_t abs_offset, int32_t* ticket);

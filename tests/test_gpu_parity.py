@@ -138,7 +138,7 @@ def test_device_resident_synthetic_vs_c_oracle(native, torch_mod, fs, bps, log2n
 
 
 def test_submit_wait_pipeline_matches_blocking_calls(native, torch_mod):
-    """Two passes in flight (adsb_submit_* / adsb_wait) must deliver exactly what the blocking call does."""
+    """Several passes in flight (adsb_submit_* / adsb_wait) must deliver exactly what the blocking call does."""
     from gr_adsb_amd import modulator as M
     n = 1 << 21
     iqs = [M.synth_iq(n, 2e6, 2000, seed) for seed in (11, 12, 13)]
@@ -147,15 +147,18 @@ def test_submit_wait_pipeline_matches_blocking_calls(native, torch_mod):
     want = [ctx.process_iq_device(t.data_ptr(), n, abs_offset=1000 * i) for i, t in enumerate(ts)]
     t0 = ctx.submit_iq_device(ts[0].data_ptr(), n, 0)
     t1 = ctx.submit_iq_device(ts[1].data_ptr(), n, 1000)
+    t2 = ctx.submit_iq_device(ts[2].data_ptr(), n, 2000)
+    assert native.MAX_IN_FLIGHT == 3
     with pytest.raises(native.AdsbError) as e:
-        ctx.submit_iq_device(ts[2].data_ptr(), n, 2000)
-    assert e.value.code == -16          # -EBUSY: both slots in flight
+        ctx.submit_iq_device(ts[0].data_ptr(), n, 0)
+    assert e.value.code == -16          # -EBUSY: every slot in flight
     with pytest.raises(native.AdsbError):
         ctx.process_iq_device(ts[2].data_ptr(), n)   # blocking calls refuse while calls are pending
     got0 = ctx.wait(t0)
-    t2 = ctx.submit_iq_device(ts[2].data_ptr(), n, 2000)
+    t3 = ctx.submit_iq_device(ts[0].data_ptr(), n, 0)     # the freed slot is reusable at once
     got1 = ctx.wait(t1)
     got2 = ctx.wait(t2)
+    assert ctx.wait(t3).tobytes() == want[0].tobytes()
     for g, w in zip((got0, got1, got2), want):
         assert g.tobytes() == w.tobytes()
     with pytest.raises(native.AdsbError):

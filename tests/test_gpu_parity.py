@@ -309,3 +309,35 @@ def test_adversarial_streams(native):
         assert_recs_equal(ctx.process_mag2(x), want, "seed %d" % seed)
         checked += len(want)
     assert checked > 100
+
+
+def test_c_abi_output_array_and_error_paths(native):
+    """The raw C ABI the way a C caller uses it: caller-owned output array, -ENOSPC with the required count,
+    pinned host buffers from adsb_host_alloc, argument validation."""
+    import ctypes
+    g = Golden("g2msps_df17")
+    lib = native.load()
+    ctx = native.Context(g.fs, g.thr)
+    want = ctx.process_iq(g.iq)
+    n_out = ctypes.c_int32(0)
+    small = np.zeros(3, dtype=native.BURST_DTYPE)
+    rc = lib.adsb_process_iq(ctx._h, ctypes.c_void_p(g.iq.ctypes.data), len(g.iq), 0, ctypes.c_void_p(small.ctypes.data), 3,
+                             ctypes.byref(n_out))
+    assert rc == -28 and n_out.value == len(want)            # -ENOSPC, count reported
+    out = np.zeros(len(want), dtype=native.BURST_DTYPE)
+    rc = lib.adsb_process_iq(ctx._h, ctypes.c_void_p(g.iq.ctypes.data), len(g.iq), 0, ctypes.c_void_p(out.ctypes.data), len(out),
+                             ctypes.byref(n_out))
+    assert rc == 0 and out.tobytes() == want.tobytes()
+    # pinned source buffer: straight DMA, same result
+    pa = native.PinnedArray(len(g.iq), np.complex64)
+    pa.array[:] = g.iq
+    assert ctx.process_iq(pa.array).tobytes() == want.tobytes()
+    # argument validation
+    assert lib.adsb_process_iq(ctx._h, None, 10, 0, None, 0, ctypes.byref(n_out)) == -22
+    assert lib.adsb_process_iq_device(ctx._h, ctypes.c_void_p(8), 10, 0, None, 0, ctypes.byref(n_out)) == -22   # misaligned
+    assert lib.adsb_framer_work(ctx._h, ctypes.c_void_p(g.x.ctypes.data), 100, 50, 0, None, 0, ctypes.byref(n_out)) == -22
+    assert b"8*sps" in lib.adsb_last_error(ctx._h)
+    assert lib.adsb_wait(ctx._h, 0, None, 0, ctypes.byref(n_out)) == -22                                         # nothing pending
+    assert lib.adsb_wait(ctx._h, 7, None, 0, ctypes.byref(n_out)) == -22
+    # empty input is a valid call
+    assert lib.adsb_process_iq(ctx._h, ctypes.c_void_p(g.iq.ctypes.data), 0, 0, None, 0, ctypes.byref(n_out)) == 0 and n_out.value == 0

@@ -68,6 +68,21 @@ def cpu_baseline(iq_host, sps, thr, reps=3):
     return len(iq_host) / best / 1e6, recs
 
 
+def cpu_baseline_threads(iq_host, sps, thr, threads):
+    """The same C port on `threads` host threads, one contiguous shard each (ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import c_oracle as C
+    n = len(iq_host)
+    per = n // threads
+    shards = [iq_host[i * per:(i + 1) * per] for i in range(threads)]
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(lambda s_: C.process_iq(s_, sps, thr), shards[:threads]))        # warm
+        t0 = time.perf_counter()
+        list(ex.map(lambda s_: C.process_iq(s_, sps, thr), shards))
+        dt = time.perf_counter() - t0
+    return per * threads / dt / 1e6
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,6 +283,11 @@ def main():
                           "the reference path incl. |IQ|^2), best of 3, host has %d cpus" % (int(np.log2(n_cpu)), os.cpu_count()),
             }
             result["bit_match"] = {"sample_bursts": int(len(crecs)), "identical": bool(match)}
+            nthr = min(64, os.cpu_count() or 1)
+            if nthr > 1:
+                result["cpu_baseline"]["all_threads"] = {
+                    "value": round(cpu_baseline_threads(host, sps, args.threshold, nthr), 1), "unit": "Msamples/s",
+                    "threads": nthr, "note": "same C port, one contiguous shard of the sample per host thread"}
         print(json.dumps(result), flush=True)
     if n_gpus > 1:
         dist.barrier()

@@ -46,9 +46,6 @@ static_assert(kWOwn == 16 && kFwd % 64 == 0, "word owners are lanes 0..15 of eac
 #define ADSB_ABLATE 0
 #endif
 constexpr int kAblate = ADSB_ABLATE;
-#ifndef ADSB_TAP_UNROLL
-#define ADSB_TAP_UNROLL 16
-#endif
 // k_detect is latency bound per workgroup: 5 resident workgroups per CU (<= 96 VGPRs, no spills) measured
 // 15-20 % faster than 4; 6 would need spills to scratch.
 #ifndef ADSB_MIN_WAVES
@@ -373,12 +370,12 @@ template <int MODE>
 __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs a) {
   __shared__ __attribute__((aligned(16))) float s_xa[kWaves][kWWin];
   __shared__ unsigned long long s_maska[kWaves][kWWords];
-  __shared__ unsigned short s_risea[kWaves][kWTile / 2];
+  __shared__ unsigned s_risea[kWaves][kWTile / 2];
 
   const int lane = threadIdx.x & 63, wave = adsb_uniform((int)(threadIdx.x >> 6));
   float* s_x = s_xa[wave];
   unsigned long long* s_mask = s_maska[wave];
-  unsigned short* s_rise = s_risea[wave];
+  unsigned* s_rise = s_risea[wave];
   const long long unit = (long long)blockIdx.x * kWaves + wave;
   const long long c0 = unit * a.chunk;
   long long c1 = c0 + a.chunk;
@@ -419,7 +416,7 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
     adsb_wave_sync();
 
     // -- B.1 rises / falls by mask algebra (framer.py:91-93); lanes 0..15 own one word each
-    const int word = lane & 15;
+    const int word = (lane < kWWords) ? lane : 0;          // lanes 0..19 hold words 0..19 (16..19 = forward halo)
     const unsigned long long M = (kAblate >= 3) ? 0ull : s_mask[word];
     const unsigned long long pb = (kAblate >= 3) ? 0ull : (word > 0) ? (s_mask[word - 1] >> 63) : (unsigned long long)pred;
     const unsigned long long sh = (M << 1) | pb;
@@ -433,14 +430,28 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
     if (anyr) {                                            // wave-uniform: quiet stretches skip everything below
       // ordered rise list: word by word (wave-uniform loop over the 16 words, empty ones skipped), lane l
       // takes bit l of the word and its slot from the prefix popcount -- no per-lane serial bit loop
+      // Each entry carries the rise index and, when the pulse ends within this or the next word (always, for
+      // real Mode-S pulses), its fall index -- found here from the mask words already in registers, which
+      // saves B.2 a dependent LDS round trip; 0xFFFF = not found yet (B.2 searches the LDS mask words).
       const int rlo = (int)(unsigned)R, rhi = (int)(unsigned)(R >> 32);
+      const int mlo = (int)(unsigned)M, mhi = (int)(unsigned)(M >> 32);
       int nr = 0;
 #pragma unroll
       for (int j = 0; j < kWOwn; ++j) {
         const unsigned long long Rj = (unsigned long long)(unsigned)adsb_readlane(rlo, j) |
                                       ((unsigned long long)(unsigned)adsb_readlane(rhi, j) << 32);
         if (Rj) {
-          if ((Rj >> lane) & 1ull) s_rise[nr + lanes_below(Rj, lane)] = (unsigned short)(64 * j + lane);
+          const unsigned long long Mj = (unsigned long long)(unsigned)adsb_readlane(mlo, j) |
+                                        ((unsigned long long)(unsigned)adsb_readlane(mhi, j) << 32);
+          const unsigned long long Mn = (unsigned long long)(unsigned)adsb_readlane(mlo, j + 1) |
+                                        ((unsigned long long)(unsigned)adsb_readlane(mhi, j + 1) << 32);
+          if ((Rj >> lane) & 1ull) {
+            const unsigned long long inv0 = (lane == 63) ? 0ull : (~Mj & (~0ull << (lane + 1)));
+            unsigned f = 0xFFFFu;
+            if (inv0) f = (unsigned)(64 * j + __builtin_ctzll(inv0));
+            else if (~Mn) f = (unsigned)(64 * (j + 1) + __builtin_ctzll(~Mn));
+            s_rise[nr + lanes_below(Rj, lane)] = (unsigned)(64 * j + lane) | (f << 16);
+          }
           nr += __popcll(Rj);
         }
       }
@@ -449,40 +460,44 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
       // -- B.2 per rise: fall, centre, 16-chip test (framer.py:113,137-147)
       int lp = -1, lp2 = -1, hflag = 0;
       for (int i = lane; i < nr; i += 64) {
-        const int r = s_rise[i];
-        int w = r >> 6;
-        const int b = r & 63;
-        unsigned long long inv = ~s_mask[w];
-        inv = (b == 63) ? 0ull : (inv & (~0ull << (b + 1)));
-        while (inv == 0ull && ++w < kWWords) inv = ~s_mask[w];
-        unsigned short res = 0;
-        if (inv == 0ull) {
+        const unsigned e0 = s_rise[i];
+        const int r = (int)(e0 & 0xFFFFu);
+        int f = (int)(e0 >> 16);
+        if (f == 0xFFFF) {                                 // run longer than a word: search the LDS mask words
+          int w = (r >> 6) + 2;
+          unsigned long long inv = 0ull;
+          while (w < kWWords && (inv = ~s_mask[w]) == 0ull) ++w;
+          f = (w < kWWords) ? w * 64 + __builtin_ctzll(inv) : -1;
+        }
+        unsigned res = 0;
+        if (f < 0) {
           if (t0 + kWWin < a.fall_hi) res = 0xFFFFu;       // pulse longer than the window: k_longrun
           else if (!a.end_is_call_end) hflag = 4;
-        } else {
-          const int f = w * 64 + __builtin_ctzll(inv);
-          if (t0 + f < a.fall_hi) {
-            const int p = (r + f) >> 1;                    // framer.py:113
-            if (i == nr - 1) lp = p;                       // centres increase with i; only the last rise of
-            else if (i == nr - 2) lp2 = p;                 // a tile can be left without a fall
-            const float hp = __fmul_rn(s_x[p], 0.5f);      // in0[pulse_idx]/2, exact
-            unsigned chips = 0;
-            if (p + 15 * half < kWWin) {                   // all 16 taps inside the LDS window
-              const float* tp = s_x + p;
-#pragma unroll ADSB_TAP_UNROLL
-              for (int k = 0; k < 16; ++k) chips |= (tp[k * half] > hp ? 1u : 0u) << k;
-            } else {                                       // rare: taps past the window come from global memory
+        } else if (t0 + f < a.fall_hi) {
+          const int p = (r + f) >> 1;                      // framer.py:113
+          if (i == nr - 1) lp = p;                         // centres increase with i; only the last rise of
+          else if (i == nr - 2) lp2 = p;                   // a tile can be left without a fall
+          unsigned chips = 0;
+          if (p + 15 * half < kWWin) {                     // all 16 taps inside the LDS window: one LDS round trip
+            const float* tp = s_x + p;
+            float tap[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tap[k] = tp[k * half];
+            const float hp = __fmul_rn(tap[0], 0.5f);      // tap 0 IS in0[pulse_idx]; /2 is exact
+#pragma unroll
+            for (int k = 0; k < 16; ++k) chips |= (tap[k] > hp ? 1u : 0u) << k;
+          } else {                                         // rare: taps past the window come from global memory
+            const float hp = __fmul_rn(s_x[p], 0.5f);
 #pragma unroll 1
-              for (int k = 0; k < 16; ++k) {
-                const int idx = p + k * half;
-                const float v = (idx < kWWin) ? s_x[idx] : xg<MODE>(a.data, a.n, t0 + idx, a.scale);
-                chips |= (v > hp ? 1u : 0u) << k;
-              }
+            for (int k = 0; k < 16; ++k) {
+              const int idx = p + k * half;
+              const float v = (idx < kWWin) ? s_x[idx] : xg<MODE>(a.data, a.n, t0 + idx, a.scale);
+              chips |= (v > hp ? 1u : 0u) << k;
             }
-            if (chips == kTemplate) res = (unsigned short)(0x8000u | (unsigned)p);
-          } else if (!a.end_is_call_end) {
-            hflag = 4;
           }
+          if (chips == kTemplate) res = 0x8000u | (unsigned)p;
+        } else if (!a.end_is_call_end) {
+          hflag = 4;
         }
         s_rise[i] = res;
       }
@@ -499,7 +514,7 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
       // -- B.3 ordered in-place compaction of the matched centres
       for (int base = 0; base < nr; base += 64) {
         const int i = base + lane;
-        const unsigned short e = (i < nr) ? s_rise[i] : (unsigned short)0;
+        const unsigned e = (i < nr) ? s_rise[i] : 0u;
         const unsigned long long mb = __ballot(e != 0);
         if (e) s_rise[nm + lanes_below(mb, lane)] = e;
         nm += __popcll(mb);
@@ -508,7 +523,7 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
 
       // -- C: append to this unit's list (stream order by construction)
       for (int i = lane; i < nm; i += 64) {
-        const unsigned short e = s_rise[i];
+        const unsigned e = s_rise[i];
         const int slot = nrec + i;
         if (slot < a.rec_cap) {
           if (e == 0xFFFFu) {

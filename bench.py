@@ -174,10 +174,10 @@ def main():
         kept = sharding.finish_shard(recs, sps, rank, ag_int, ungated, ag_obj, inplace=inplace)
         return len(kept)
 
-    def ag_int(v):
-        out = [torch.zeros(1, dtype=torch.int64) for _ in range(n_gpus)]
-        dist.all_gather(out, torch.tensor([int(v)], dtype=torch.int64))      # 8 bytes per rank, host side (gloo)
-        return [int(t[0]) for t in out]
+    def ag_int(pair):
+        out = [torch.zeros(2, dtype=torch.int64) for _ in range(n_gpus)]
+        dist.all_gather(out, torch.tensor([int(pair[0]), int(pair[1])], dtype=torch.int64))   # 16 bytes per rank, host side (gloo)
+        return [(int(t[0]), int(t[1])) for t in out]
 
     def ag_obj(o):
         out = [None] * n_gpus

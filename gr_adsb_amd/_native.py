@@ -284,6 +284,7 @@ def stitch(cands, sps):
 
 
 BURST_HEAD = 16
+MAX_HEAD = 4096          # upper bound on head_cands callers use
 EOB_NONE = -(1 << 60)
 
 
@@ -302,6 +303,23 @@ def shard_fixup(recs, sps, eob_in, inplace=False):
     if rc != 0:
         raise AdsbError(rc, "adsb_shard_fixup")
     return recs[:nk.value]
+
+
+SYNC_ALWAYS = (1 << 62)
+
+
+def shard_head_sync(recs, sps):
+    """What decides -- for ANY incoming eob -- whether shard_fixup can succeed on this shard: the largest offset
+    of a head-region centre that lies more than 63*sps after its predecessor (fixup succeeds iff that offset is
+    beyond the incoming eob), SYNC_ALWAYS when the whole shard fits in the head region, EOB_NONE if there is no
+    such centre."""
+    fl = recs["flags"]
+    nh = int(np.count_nonzero(fl[:MAX_HEAD] & BURST_HEAD)) if len(recs) else 0
+    if nh == len(recs):
+        return SYNC_ALWAYS
+    off = recs["offset"][:nh]
+    idx = np.flatnonzero(np.diff(off) > 63 * sps)
+    return int(off[idx[-1] + 1]) if len(idx) else EOB_NONE
 
 
 def shard_tail(recs, sps):

@@ -97,3 +97,34 @@ def test_stitch_is_the_reference_gate(native):
     c["offset"] = [5, 5]
     with pytest.raises(native.AdsbError):
         native.stitch(c, 2)
+
+
+def test_head_sync_predicts_fixup_and_fixup_is_exact(native):
+    """Host-only: for random centre lists, (1) shard_head_sync() > eob_in  <=>  adsb_shard_fixup succeeds,
+    (2) when it succeeds the result equals the sequential gate started from eob_in."""
+    from oracle import adsb_oracle as O
+    rng = np.random.default_rng(7)
+    hits = misses = 0
+    for trial in range(400):
+        sps = int(rng.choice([2, 8, 20]))
+        gate = 63 * sps
+        n = int(rng.integers(1, 200))
+        off = np.cumsum(rng.integers(1, 3 * gate, n)).astype(np.int64) + 1000
+        head_n = int(rng.choice([1, 2, 8, 64]))
+        fresh = O.resolve_candidates(off, sps)                        # what the device gate keeps with fresh state
+        sel = fresh | (np.arange(n) < head_n)                          # delivered: kept + the whole head region
+        recs = np.zeros(int(sel.sum()), dtype=native.BURST_DTYPE)
+        recs["offset"] = off[sel]
+        recs["flags"] = (np.where(fresh[sel], 2, 0) | np.where(np.arange(n)[sel] < head_n, 16, 0)).astype(np.uint16)
+        eob_in = int(rng.choice([native.EOB_NONE, 900, 1000 + int(rng.integers(0, 4 * gate)), int(off[min(n - 1, 3)]) + gate]))
+        want = off[O.resolve_candidates(off, sps, prev_eob=eob_in)]
+        got = native.shard_fixup(recs, sps, eob_in)
+        predicted = native.shard_head_sync(recs, sps) > eob_in
+        assert predicted == (got is not None)
+        if got is not None:
+            assert np.array_equal(got["offset"], want)
+            assert np.all(got["flags"] & 2) and not np.any(got["flags"] & 16)
+            hits += 1
+        else:
+            misses += 1
+    assert hits > 100 and misses > 10

@@ -39,10 +39,10 @@ def _worker(rank, world, port, head, bps, q):
     def shard(head_cands):
         return simlib.sim_shard(0, iq[p["lo"]:p["hi"]], p["lo"], p["own_lo"], p["own_hi"], n, fs, 0.01, head_cands=head_cands)[0]
 
-    def ag_int(v):
-        out = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(out, torch.tensor([int(v)], dtype=torch.int64))
-        return [int(t[0]) for t in out]
+    def ag_int(pair):
+        out = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(out, torch.tensor([int(pair[0]), int(pair[1])], dtype=torch.int64))
+        return [(int(t[0]), int(t[1])) for t in out]
 
     def ag_obj(o):
         out = [None] * world

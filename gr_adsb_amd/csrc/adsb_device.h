@@ -19,7 +19,8 @@
 //
 // This header contains device code only and includes nothing.  The includer provides the HIP device
 // environment plus `adsb_wave_sync()` (a wavefront-level execution/LDS ordering point), `adsb_uniform(int)`
-// (marks a wavefront-uniform value so it lives in a scalar register) and `adsb_readlane(int, lane)`: the
+// (marks a wavefront-uniform value so it lives in a scalar register), `adsb_readlane(int, lane)` and
+// `adsb_bitrep32(u32) -> u64` (every bit doubled: s_bitreplicate_b64_b32): the
 // product translation unit adsb_hip.hip maps them to __builtin_amdgcn_wave_barrier() / _readfirstlane() /
 // _readlane(); tests/sim/sim_driver.cpp includes the test-only SIMT emulator instead, so the very same
 // kernels run on a machine without a GPU.
@@ -319,14 +320,17 @@ __device__ __forceinline__ void span_commit(const Span<MODE, COUNT, NWAVES>& sp,
       m.y = mag2f(sp.q[k].z, sp.q[k].w);
       if (act) *reinterpret_cast<float2*>(&sx[g + 2 * lane]) = m;
       if (kAblate < 3) {
-        // lane l holds samples 2l, 2l+1: E/O masks -> natural-order words (framer.py:83-84)
+        // lane l holds samples 2l, 2l+1: the even/odd threshold masks (framer.py:83-84) are interleaved into
+        // natural-order words on the SCALAR unit: s_bitreplicate doubles every bit, the masks pick the slot
         const unsigned long long E = __ballot(act && m.x >= thr), O = __ballot(act && m.y >= thr);
-        const unsigned long long sel = (lane & 1) ? O : E;
-        const unsigned long long w0 = __ballot((sel >> (lane >> 1)) & 1ull);
-        if (lane == 0) smask[g >> 6] = w0;
+        const unsigned long long w0 = (adsb_bitrep32((unsigned)E) & 0x5555555555555555ull) |
+                                      (adsb_bitrep32((unsigned)O) & 0xAAAAAAAAAAAAAAAAull);
         if (S::SHARE >= 128) {
-          const unsigned long long w1 = __ballot((sel >> (32 + (lane >> 1))) & 1ull);
-          if (lane == 0) smask[(g >> 6) + 1] = w1;
+          const unsigned long long w1 = (adsb_bitrep32((unsigned)(E >> 32)) & 0x5555555555555555ull) |
+                                        (adsb_bitrep32((unsigned)(O >> 32)) & 0xAAAAAAAAAAAAAAAAull);
+          if (lane == 0) { smask[g >> 6] = w0; smask[(g >> 6) + 1] = w1; }
+        } else if (lane == 0) {
+          smask[g >> 6] = w0;
         }
       }
     } else {

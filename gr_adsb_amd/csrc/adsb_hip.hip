@@ -21,6 +21,12 @@ __device__ __forceinline__ void adsb_wave_sync() {
 
 __device__ __forceinline__ int adsb_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int adsb_readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// bit i of x -> bits 2i and 2i+1 (scalar unit; the argument must be wave-uniform)
+__device__ __forceinline__ unsigned long long adsb_bitrep32(unsigned x) {
+  unsigned long long r;
+  asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(r) : "s"(x));
+  return r;
+}
 
 #include "adsb_device.h"
 #include "adsb_plan.h"

@@ -195,6 +195,11 @@ inline void adsb_wave_sync() {
 
 inline int adsb_uniform(int v) { return v; }
 inline int adsb_readlane(int v, int lane) { return hipsim_shfl_idx(v, lane); }
+inline unsigned long long adsb_bitrep32(unsigned x) {
+  unsigned long long r = 0;
+  for (int i = 0; i < 32; ++i) if ((x >> i) & 1u) r |= 3ull << (2 * i);
+  return r;
+}
 
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline unsigned long long __brevll(unsigned long long v) {

@@ -43,10 +43,14 @@ static_assert(kWOwn == 16 && kFwd % 64 == 0, "word owners are lanes 0..15 of eac
 
 // Tuning aid (tools/kbench.py builds side copies of the library with -DADSB_ABLATE=k to time phases of
 // k_detect in isolation); the shipped library is always built with 0 = nothing skipped.
+//   4 loads only | 3 + LDS commit | 2 + threshold masks, rise/fall flags | 21 + rise lists | 22 + falls, centres
+//   23 + the 16 taps (matches discarded) | 0 everything.  Measured round 1 (2 Msps / 8 Msps dense, ms):
+//   0.347 | 0.355 | 0.365/0.363 | 0.380/0.410 | 0.393/0.424 | 0.407/0.441 | 0.41-0.42/0.43-0.44
 #ifndef ADSB_ABLATE
 #define ADSB_ABLATE 0
 #endif
 constexpr int kAblate = ADSB_ABLATE;
+constexpr bool kNoMasks = kAblate >= 3 && kAblate < 20;   // 3, 4: streaming only; 21..24 probe the rise path
 // k_detect is latency bound per workgroup: 5 resident workgroups per CU (<= 96 VGPRs, no spills) measured
 // 15-20 % faster than 4; 6 would need spills to scratch.
 #ifndef ADSB_MIN_WAVES
@@ -319,7 +323,7 @@ __device__ __forceinline__ void span_commit(const Span<MODE, COUNT, NWAVES>& sp,
       m.x = mag2f(sp.q[k].x, sp.q[k].y);
       m.y = mag2f(sp.q[k].z, sp.q[k].w);
       if (act) *reinterpret_cast<float2*>(&sx[g + 2 * lane]) = m;
-      if (kAblate < 3) {
+      if (!kNoMasks) {
         // lane l holds samples 2l, 2l+1: the even/odd threshold masks (framer.py:83-84) are interleaved into
         // natural-order words on the SCALAR unit: s_bitreplicate doubles every bit, the masks pick the slot
         const unsigned long long E = __ballot(act && m.x >= thr), O = __ballot(act && m.y >= thr);
@@ -342,7 +346,7 @@ __device__ __forceinline__ void span_commit(const Span<MODE, COUNT, NWAVES>& sp,
         m.w = mag2_iq16(__builtin_bit_cast(unsigned, sp.q[k].w), scale);
       }
       if (act) *reinterpret_cast<float4*>(&sx[g + 4 * lane]) = m;
-      if (kAblate < 3) {
+      if (!kNoMasks) {
         const unsigned long long A = __ballot(act && m.x >= thr), B = __ballot(act && m.y >= thr);
         const unsigned long long C = __ballot(act && m.z >= thr), D = __ballot(act && m.w >= thr);
         const int c = lane & 3;
@@ -421,14 +425,14 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
 
     // -- B.1 rises / falls by mask algebra (framer.py:91-93); lanes 0..15 own one word each
     const int word = (lane < kWWords) ? lane : 0;          // lanes 0..19 hold words 0..19 (16..19 = forward halo)
-    const unsigned long long M = (kAblate >= 3) ? 0ull : s_mask[word];
-    const unsigned long long pb = (kAblate >= 3) ? 0ull : (word > 0) ? (s_mask[word - 1] >> 63) : (unsigned long long)pred;
+    const unsigned long long M = kNoMasks ? 0ull : s_mask[word];
+    const unsigned long long pb = kNoMasks ? 0ull : (word > 0) ? (s_mask[word - 1] >> 63) : (unsigned long long)pred;
     const unsigned long long sh = (M << 1) | pb;
     const long long wbase = t0 + 64ll * word;
     const unsigned long long own = (lane < 16) ? bit_range(a.scan_lo - wbase, a.scan_hi - wbase) : 0ull;
     unsigned long long R = M & ~sh & own;
     const unsigned long long Fm = ~M & sh & own;
-    const unsigned long long anyr = (kAblate >= 2) ? 0ull : __ballot(R != 0ull), anyf = __ballot(Fm != 0ull);
+    const unsigned long long anyr = (kAblate >= 2 && kAblate < 20) ? 0ull : __ballot(R != 0ull), anyf = __ballot(Fm != 0ull);
     uflags |= (anyr ? 1u : 0u) | (anyf ? 2u : 0u);
     int nm = 0;
     if (anyr) {                                            // wave-uniform: quiet stretches skip everything below
@@ -460,6 +464,7 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
         }
       }
       adsb_wave_sync();
+      if (kAblate == 21) nr = 0;                           // (tuning aid: list built, nothing evaluated)
 
       // -- B.2 per rise: fall, centre, 16-chip test (framer.py:113,137-147)
       int lp = -1, lp2 = -1, hflag = 0;
@@ -482,7 +487,9 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
           if (i == nr - 1) lp = p;                         // centres increase with i; only the last rise of
           else if (i == nr - 2) lp2 = p;                   // a tile can be left without a fall
           unsigned chips = 0;
-          if (p + 15 * half < kWWin) {                     // all 16 taps inside the LDS window: one LDS round trip
+          if (kAblate == 22) { chips = (unsigned)p & 1u; }  // (tuning aid: no taps)
+          else if (kAblate == 24) { chips = (i == 0) ? kTemplate : 0u; }   // (tuning aid: no taps, one match per tile)
+          else if (p + 15 * half < kWWin) {                // all 16 taps inside the LDS window: one LDS round trip
             const float* tp = s_x + p;
             float tap[16];
 #pragma unroll
@@ -499,7 +506,8 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
               chips |= (v > hp ? 1u : 0u) << k;
             }
           }
-          if (chips == kTemplate) res = 0x8000u | (unsigned)p;
+          if (kAblate == 23) { if (chips == kTemplate) hflag |= 8; }   // (tuning aid: taps read and used, no match kept)
+          else if (chips == kTemplate) res = 0x8000u | (unsigned)p;
         } else if (!a.end_is_call_end) {
           hflag = 4;
         }

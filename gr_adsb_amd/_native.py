@@ -17,6 +17,10 @@ assert BURST_DTYPE.itemsize == 32
 FLAG_TIMING = 1
 BURST_DEMOD = 1
 BURST_KEPT = 2
+BURST_PARITY_OK = 32     # Mode S parity pre-filter bits (include/adsb_hip.h; decoder.py:550-688)
+BURST_LONG = 64
+BURST_KNOWN_DF = 128
+BURST_DF_SHIFT = 8
 MAX_IN_FLIGHT = 3
 
 EXPORTS = [
@@ -24,7 +28,7 @@ EXPORTS = [
     "adsb_process_iq", "adsb_process_mag2", "adsb_process_iq_device", "adsb_process_mag2_device", "adsb_last_result",
     "adsb_submit_iq_device", "adsb_submit_mag2_device", "adsb_submit_iq16_device", "adsb_submit_shard_device", "adsb_wait",
     "adsb_set_iq16_scale", "adsb_process_iq16", "adsb_process_iq16_device",
-    "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_get_stats",
+    "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_mode_s_syndrome", "adsb_get_stats",
     "adsb_reset_stats", "adsb_last_error", "adsb_host_alloc", "adsb_host_free",
 ]
 
@@ -90,6 +94,8 @@ def load():
     lib.adsb_stitch.argtypes = [vp, i32, c.c_int, c.POINTER(i32)]
     lib.adsb_snr_db.argtypes = [f32, f32]
     lib.adsb_snr_db.restype = f32
+    lib.adsb_mode_s_syndrome.argtypes = [vp, c.POINTER(i32), c.POINTER(i32)]
+    lib.adsb_mode_s_syndrome.restype = c.c_uint32
     lib.adsb_get_stats.argtypes = [vp, c.POINTER(Stats)]
     lib.adsb_reset_stats.argtypes = [vp]
     lib.adsb_host_alloc.argtypes = [c.POINTER(vp), c.c_size_t]
@@ -232,6 +238,7 @@ class Context:
                                            ctypes.c_void_p(tags.ctypes.data), nt, ctypes.c_void_p(bits.ctypes.data),
                                            ctypes.c_void_p(ok.ctypes.data),
                                            ctypes.c_void_p(ratio.ctypes.data) if want_ratio else None))
+        self.last_demod_flags = ok        # ok[t] = BURST_DEMOD | parity pre-filter bits (0 = dropped)
         return bits, ok.astype(bool), ratio
 
     def shard_device(self, fmt, dev_ptr, n, origin, own_lo, own_hi, stream_len, head_cands=0):
@@ -333,6 +340,26 @@ def shard_tail(recs, sps):
 
 def snr_db_c(peak, median):
     return load().adsb_snr_db(float(peak), float(median))
+
+
+def burst_df(recs):
+    """Downlink format of every record (decoder.py:551), from the device's pre-filter bits."""
+    return (recs["flags"] >> BURST_DF_SHIFT) & 31
+
+
+def parity_ok(recs):
+    """True where the decoder's check_parity() will pass without an aircraft table (DF 11/17/18/19, syndrome 0)."""
+    return (recs["flags"] & BURST_PARITY_OK) != 0
+
+
+def mode_s_syndrome(bits14):
+    """(syndrome, df, nbits) of one 14-byte payload via the C helper: the announced address for the
+    address/parity formats (decoder.py:577,647)."""
+    b = np.ascontiguousarray(bits14, dtype=np.uint8)
+    assert b.size == 14
+    df, nb = ctypes.c_int32(), ctypes.c_int32()
+    syn = load().adsb_mode_s_syndrome(b.ctypes.data_as(ctypes.c_void_p), ctypes.byref(df), ctypes.byref(nb))
+    return int(syn), df.value, nb.value
 
 
 def unpack_bits(bits14):

@@ -81,11 +81,29 @@ class framer(gr.sync_block):
         return N
 
 
+_DF_WEIGHTS = np.array([16, 8, 4, 2, 1])
+_PI_FORMATS = (11, 17, 18, 19)
+
+
+def _prefilter_pass(flags, df):
+    """A PDU can still pass decoder.check_parity(): known DF, and for the parity/interrogator formats a zero
+    syndrome (address/parity formats need the decoder's aircraft table and always go through)."""
+    if not flags & _native.BURST_KNOWN_DF:
+        return False
+    return bool(flags & _native.BURST_PARITY_OK) if df in _PI_FORMATS else True
+
+
 class demod(gr.sync_block):
     """PPM bit slicer / PDU publisher (reference python/adsb/demod.py:31-136)."""
 
-    def __init__(self, fs, device=0):
+    def __init__(self, fs, device=0, parity_filter=False):
+        """parity_filter (extension, default off = the reference's behaviour: every PDU is published): when
+        True, PDUs the decoder's check_parity() would reject outright -- unknown DF, or DF 11/17/18/19 with
+        a non-zero syndrome (decoder.py:560-688) -- are counted in `self.filtered` and not published.  Only
+        for decoders run with error_corr="None": a dropped PDU can no longer be repaired by their FEC."""
         gr.sync_block.__init__(self, name="demod", in_sig=[np.float32], out_sig=[np.float32])
+        self.parity_filter = bool(parity_filter)
+        self.filtered = 0
         self.fs = fs
         assert self.fs % SYMBOL_RATE == 0, \
             "ADS-B Demodulator is designed to operate on an integer number of samples per symbol, not %f sps" % (self.fs / SYMBOL_RATE)
@@ -112,9 +130,13 @@ class demod(gr.sync_block):
             offs = np.array([t.offset for t in tags], dtype=np.int64)
             # demod.py:79 indexes with nitems_written(0); equal to nitems_read(0) for this sync block
             bits, ok, ratio = self._ctx.demod_work(in0, self.nitems_written(0), offs, want_ratio=self.want_confidence)
+            pf = self._ctx.last_demod_flags
             for i, tag in enumerate(tags):
                 if not ok[i]:
                     self.straddled_packet = 1     # demod.py:130-133: dropped
+                    continue
+                if self.parity_filter and not _prefilter_pass(int(pf[i]), int(bits[i][:5] @ _DF_WEIGHTS)):
+                    self.filtered += 1
                     continue
                 value = pmt.to_python(tag.value)
                 snr = value[1]

@@ -63,7 +63,31 @@ enum RecFlags : unsigned {
   kNoMatch = 4u,   // placeholder whose long pulse did not match the preamble
   kPending = 8u,   // placeholder waiting for k_longrun
   kHead = 16u,     // shard mode: one of the first centres of the shard, delivered whether gated or not
+  // Mode S parity pre-filter (decoder.py:550-556 DF, :560-688 check_parity), kDemod only:
+  kParityOk = 32u,   // DF 11/17/18/19 (parity/interrogator field) and the 24-bit syndrome is zero
+  kLongFmt = 64u,    // DF 16/17/18/19/20/21/24: 112-bit reply (else the decoder reads 56 bits)
+  kKnownDf = 128u,   // DF is one the reference decoder checks parity for (0,4,5,11,16-21,24)
+  kDfShift = 8u,     // bits 8..12: the downlink format (first five bits, MSB first)
 };
+
+// x^j mod G, j = 0..111, G = x^24 + 0xFFF409 (decoder.py:268-269: the 25 coefficients spell 0x1FFF409).  The
+// Mode S syndrome is linear in the message bits: bit i of an L-bit reply contributes x^(L-1-i) mod G, so
+// compute_crc(bits[0:L-24]) ^ bits[L-24:L] (decoder.py:693-714 and its callers) is one XOR-reduction.
+struct CrcTab { unsigned r[112]; };
+constexpr CrcTab make_crc_tab() {
+  CrcTab t{};
+  unsigned v = 1;
+  for (int j = 0; j < 112; ++j) {
+    t.r[j] = v;
+    v <<= 1;
+    if (v & 0x1000000u) v ^= 0x1FFF409u;
+  }
+  return t;
+}
+// DF membership sets of decoder.py:565,604,636,669 as bit masks over the 5-bit DF
+constexpr unsigned kDfShortSet = (1u << 0) | (1u << 4) | (1u << 5) | (1u << 11);
+constexpr unsigned kDfLongSet = (1u << 16) | (1u << 17) | (1u << 18) | (1u << 19) | (1u << 20) | (1u << 21) | (1u << 24);
+constexpr unsigned kDfPiSet = (1u << 11) | (1u << 17) | (1u << 18) | (1u << 19);
 
 // 32-byte burst record: w0 = stream offset (int64); w1 = peak | median<<32 (float bits);
 // w2 = bits 0..63 as bytes 0..7 (first bit = MSB of byte 0); w3 = bytes 8..13 | flags<<48.
@@ -189,6 +213,27 @@ __device__ __forceinline__ float key_f32(unsigned k) {
   return __builtin_bit_cast(float, k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
+// Mode S parity pre-filter for one sliced burst held by a wavefront: lane holds message bits `lane` (bitA) and
+// `64+lane` (bitB, lanes 0..47); ma = ballot(bitA).  Returns kParityOk | kLongFmt | kKnownDf | DF << kDfShift
+// (wave-uniform): the syndromes of the 112- and of the 56-bit reading are XOR-reduced side by side.
+__device__ __forceinline__ unsigned parity_prefilter(bool bitA, bool bitB, unsigned long long ma, int lane) {
+  static constexpr CrcTab tab = make_crc_tab();
+  unsigned sl = (bitA ? tab.r[111 - lane] : 0u) ^ ((bitB && lane < 48) ? tab.r[(47 - lane) & 63] : 0u);
+  unsigned ss = (bitA && lane < 56) ? tab.r[(55 - lane) & 63] : 0u;
+  for (int d2 = 32; d2 >= 1; d2 >>= 1) {
+    sl ^= __shfl_xor(sl, d2);
+    ss ^= __shfl_xor(ss, d2);
+  }
+  const unsigned df = (unsigned)(__brevll(ma & 31ull) >> 59);                              // decoder.py:551
+  const unsigned dfb = 1u << df;
+  const bool lng = (dfb & kDfLongSet) != 0, known = lng || (dfb & kDfShortSet) != 0;
+  unsigned flags = df << kDfShift;
+  if (lng) flags |= kLongFmt;
+  if (known) flags |= kKnownDf;
+  if ((dfb & kDfPiSet) && (lng ? sl : ss) == 0) flags |= kParityOk;                         // decoder.py:625,679
+  return flags;
+}
+
 template <int MODE>
 __device__ void emit_record(const DetectArgs& a, long long p, unsigned xflags, Rec* out, int lane) {
   const void* d = a.data;
@@ -241,11 +286,13 @@ __device__ void emit_record(const DetectArgs& a, long long p, unsigned xflags, R
     const unsigned B = (cle >= ((nwin - 1) >> 1) + 2) ? A : m;
     med = __fmul_rn(__fadd_rn(key_f32(A), key_f32(B)), 0.5f);          // f32(a+b)/2
   }
-  const unsigned long long ma = __ballot(dem && x1 > x0), mb = __ballot(dem1 && y1 > y0);   // demod.py:95
+  const bool bitA = dem && x1 > x0, bitB = dem1 && y1 > y0;                                // demod.py:95
+  const unsigned long long ma = __ballot(bitA), mb = __ballot(bitB);
+  const unsigned pflags = parity_prefilter(bitA, bitB, ma, lane);
   if (lane == 0) {
     const unsigned long long ra = __builtin_bswap64(__brevll(ma));
     const unsigned long long rb = __builtin_bswap64(__brevll(mb)) & 0xFFFFFFFFFFFFull;
-    const unsigned flags = (dem ? kDemod : 0u) | xflags;
+    const unsigned flags = (dem ? (kDemod | pflags) : 0u) | xflags;
     Rec r;
     r.w[0] = (unsigned long long)(a.origin + p);
     r.w[1] = (unsigned long long)__builtin_bit_cast(unsigned, peak) |
@@ -868,12 +915,13 @@ __global__ void __launch_bounds__(kThreads) k_slice(const void* data, long long 
       }
     }
     const unsigned long long ma = __ballot(b0), mb = __ballot(b1);
+    const unsigned pflags = parity_prefilter(b0, b1, ma, lane);
     if (lane == 0) {
       const unsigned long long ra = __builtin_bswap64(__brevll(ma));
       const unsigned long long rb = __builtin_bswap64(__brevll(mb));
       for (int k = 0; k < 8; ++k) bits14[(long long)t * 14 + k] = (unsigned char)(ra >> (8 * k));
       for (int k = 0; k < 6; ++k) bits14[(long long)t * 14 + 8 + k] = (unsigned char)(rb >> (8 * k));
-      ok[t] = dem ? 1 : 0;
+      ok[t] = dem ? (unsigned char)(1u | (pflags & 0xE0u)) : 0;     // kDemod | kParityOk | kLongFmt | kKnownDf
     }
     if (ratio && dem) {
       ratio[(long long)t * 112 + lane] = q0;

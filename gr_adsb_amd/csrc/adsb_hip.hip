@@ -372,6 +372,20 @@ extern "C" {
 
 int adsb_abi_version(void) { return ADSB_ABI_VERSION; }
 
+uint32_t adsb_mode_s_syndrome(const uint8_t bits[14], int32_t* df_out, int32_t* nbits_out) {
+  // decoder.py:551 (DF), :565,604,636,669 (format sets), :693-714 (compute_crc); same table as the device
+  static constexpr CrcTab tab = make_crc_tab();
+  const unsigned df = bits[0] >> 3, dfb = 1u << df;
+  const bool lng = (dfb & kDfLongSet) != 0, known = lng || (dfb & kDfShortSet) != 0;
+  const int L = lng ? 112 : 56;
+  uint32_t syn = 0;
+  for (int i = 0; i < L; ++i)
+    if ((bits[i >> 3] >> (7 - (i & 7))) & 1) syn ^= tab.r[L - 1 - i];
+  if (df_out) *df_out = (int32_t)df;
+  if (nbits_out) *nbits_out = known ? L : 0;
+  return syn;
+}
+
 float adsb_snr_db(float peak, float median) {
   // framer.py:157 under NumPy-2 promotion: every operation in float32
   volatile float q = peak / median;

@@ -41,6 +41,15 @@ extern "C" {
 #define ADSB_BURST_DEMOD 1u /* eob inside the demod input: bits[] valid, a PDU is published (demod.py:82) */
 #define ADSB_BURST_KEPT 2u  /* passed the framer's re-trigger gate (framer.py:121) */
 #define ADSB_BURST_HEAD 16u /* shard mode: part of the shard's head region (see adsb_shard_device) */
+/* Mode S parity pre-filter, computed on the device for every burst with ADSB_BURST_DEMOD:
+ * what the decoder's first two steps (decoder.py:550-556 decode_header, :560-688 check_parity) will find,
+ * so a consumer can drop garbage PDUs before they reach the (scalar, per-message) decoder.  Advisory: the
+ * bits and every other field are unchanged, and the reference-compatible blocks publish all PDUs. */
+#define ADSB_BURST_PARITY_OK 32u /* DF 11/17/18/19 and crc(bits[0:L-24]) == bits[L-24:L] (decoder.py:625,679) */
+#define ADSB_BURST_LONG 64u      /* DF 16-21/24: 112-bit reply (decoder.py:636,669); else the 56-bit reading */
+#define ADSB_BURST_KNOWN_DF 128u /* DF is one check_parity() handles: 0,4,5,11,16,17,18,19,20,21,24 */
+#define ADSB_BURST_DF_SHIFT 8    /* (flags >> 8) & 31 = downlink format (decoder.py:551) */
+#define ADSB_BURST_DF(flags) (((flags) >> ADSB_BURST_DF_SHIFT) & 31u)
 
 typedef struct adsb_ctx adsb_ctx;
 
@@ -134,8 +143,9 @@ int adsb_framer_work(adsb_ctx* ctx, const float* in0, int64_t n_in0, int64_t N, 
 
 /* demod.work(): in0 = this call's n input floats, nitems_read = nitems_read(0) (== nitems_written(0)
  * for a sync block); tag_offsets = absolute offsets of the "burst" tags inside [nitems_read,
- * nitems_read+n).  bits112: ntags*112 bytes of 0/1 (the u8vector the PDU carries); ok[t] = 1 when the
- * burst was demodulated, 0 when it straddles the end of the chunk and is dropped (demod.py:82,130-133).
+ * nitems_read+n).  bits112: ntags*112 bytes of 0/1 (the u8vector the PDU carries); ok[t] != 0 when the
+ * burst was demodulated, 0 when it straddles the end of the chunk and is dropped (demod.py:82,130-133);
+ * a non-zero ok[t] is ADSB_BURST_DEMOD | the pre-filter bits ADSB_BURST_PARITY_OK / _LONG / _KNOWN_DF.
  * ratio (optional, may be NULL): ntags*112 floats bit1_amp/bit0_amp; 10*log10 of it is
  * demod.bit_confidence (demod.py:101). */
 int adsb_demod_work(adsb_ctx* ctx, const float* in0, int64_t n, int64_t nitems_read,
@@ -166,6 +176,13 @@ int adsb_stitch(adsb_burst* cands, int32_t n, int sps, int32_t* n_kept);
  * a SIMD routine on some hosts, so the reference's SNR bits are host dependent; the Python shim finalises
  * SNR with NumPy from (peak, median) -- those two ARE bit exact -- and this helper is for C callers. */
 float adsb_snr_db(float peak, float median);
+
+/* Host helper for the address/parity formats (DF 0/4/5/16/20/21/24), whose check needs the consumer's
+ * aircraft table: returns crc(bits[0:L-24]) ^ bits[L-24:L] -- the announced address `aa` of
+ * decoder.py:577,647 (0 for a clean DF 11/17/18/19) -- for the DF's length L; *df = downlink format,
+ * *nbits = 56 / 112, or 0 for a DF check_parity() does not know (the 56-bit reading is returned).
+ * Pure host arithmetic on one 14-byte payload; out pointers may be NULL. */
+uint32_t adsb_mode_s_syndrome(const uint8_t bits[14], int32_t* df, int32_t* nbits);
 
 int adsb_get_stats(adsb_ctx* ctx, adsb_stats* out);
 int adsb_reset_stats(adsb_ctx* ctx);

@@ -132,3 +132,30 @@ int64_t oracle_process_iq(const float* iq, int64_t n, int sps, float thr, int64_
   free(x);
   return r;
 }
+
+/* ---- Mode S parity pre-filter: decoder.py:551 (DF), :560-688 (check_parity), :693-714
+ * (compute_crc: bit-serial division by the 25-coefficient generator of decoder.py:269).  bits14 = the 112
+ * PDU bits packed MSB first.  Returns crc(bits[0:L-24]) ^ bits[L-24:L] for the DF's length L (56-bit
+ * reading for DFs the decoder does not know); *flags_out = PARITY_OK 32 | LONG 64 | KNOWN_DF 128 | DF<<8. */
+uint32_t oracle_mode_s_parity(const uint8_t* bits14, int* df_out, int* nbits_out, unsigned* flags_out) {
+  static const int POLY[25] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 1};
+  int b[112 + 24];
+  for (int k = 0; k < 112; ++k) b[k] = (bits14[k >> 3] >> (7 - (k & 7))) & 1;
+  int df = 0;
+  for (int k = 0; k < 5; ++k) df = (df << 1) | b[k];
+  const int is_long = df == 16 || df == 17 || df == 18 || df == 19 || df == 20 || df == 21 || df == 24;
+  const int is_short = df == 0 || df == 4 || df == 5 || df == 11;
+  const int L = is_long ? 112 : 56;
+  int w[112];
+  for (int k = 0; k < L - 24; ++k) w[k] = b[k];
+  for (int k = L - 24; k < L; ++k) w[k] = 0;                       /* decoder.py:704 */
+  for (int i = 0; i < L - 24; ++i)                                 /* decoder.py:706-711 */
+    if (w[i]) for (int k = 0; k < 25; ++k) w[i + k] ^= POLY[k];
+  uint32_t syn = 0;
+  for (int k = L - 24; k < L; ++k) syn = (syn << 1) | (uint32_t)(w[k] ^ b[k]);
+  const int pi = df == 11 || df == 17 || df == 18 || df == 19;
+  if (df_out) *df_out = df;
+  if (nbits_out) *nbits_out = is_long ? 112 : (is_short ? 56 : 0);
+  if (flags_out) *flags_out = ((unsigned)df << 8) | (is_long ? 64u : 0u) | ((is_long || is_short) ? 128u : 0u) | ((pi && syn == 0) ? 32u : 0u);
+  return syn;
+}

@@ -227,3 +227,50 @@ def resolve_candidates(cand_offsets, sps, prev_eob=-1):
             keep[i] = True
             eob = int(p) + 63 * sps
     return keep
+
+
+# ---- Mode S parity pre-filter ------------------------------------------------------
+# Restates the part of the reference DECODER that decides whether a PDU survives (decoder.py:550-556
+# decode_header's DF, :560-688 check_parity, :693-714 compute_crc), so the flags the device attaches to
+# every burst can be checked.  Pinned against the imported reference decoder by
+# tests/test_oracle_vs_reference.py and against tests/golden/g_parity.npz.
+CRC_POLY = np.array([1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 1], dtype=np.int64)  # decoder.py:269
+DF_SHORT = (0, 4, 5, 11)                  # decoder.py:565,604: 56-bit replies
+DF_LONG = (16, 17, 18, 19, 20, 21, 24)    # decoder.py:636,669: 112-bit replies
+DF_PI = (11, 17, 18, 19)                  # parity/interrogator field: passes iff pi == crc (decoder.py:623,677)
+FLAG_PARITY_OK, FLAG_LONG, FLAG_KNOWN_DF, DF_SHIFT = 32, 64, 128, 8
+
+
+def compute_crc(data_bits):
+    """decoder.py:693-714 over rows: long division of data * x^24 by the generator, remainder = 24 bits."""
+    d = np.asarray(data_bits, dtype=np.int64)
+    d = d.reshape(-1, d.shape[-1])
+    nd = d.shape[1]
+    w = np.concatenate([d, np.zeros((d.shape[0], 24), np.int64)], axis=1)   # decoder.py:704
+    for ii in range(nd):                                                      # decoder.py:706-711
+        rows = w[:, ii] == 1
+        w[rows, ii:ii + 25] ^= CRC_POLY
+    return w[:, nd:nd + 24]
+
+
+def mode_s_parity(bits112):
+    """[n,112] PDU bits -> dict(df, nbits, syndrome, flags): `syndrome` = crc ^ last 24 bits of the reply
+    (== pi ^ crc for DF 11/17/18/19, == the announced address `aa` for the address/parity formats,
+    decoder.py:577,647); `flags` as the device sets them (ADSB_BURST_PARITY_OK | _LONG | _KNOWN_DF | DF<<8)."""
+    b = np.asarray(bits112, dtype=np.int64).reshape(-1, 112)
+    n = b.shape[0]
+    wts5 = 1 << np.arange(4, -1, -1)
+    wts24 = 1 << np.arange(23, -1, -1)
+    df = b[:, :5] @ wts5                                                     # decoder.py:551
+    is_long = np.isin(df, DF_LONG)
+    known = is_long | np.isin(df, DF_SHORT)
+    nbits = np.where(is_long, 112, np.where(known, 56, 0))
+    syn = np.zeros(n, np.int64)
+    for L, rows in ((112, is_long), (56, ~is_long)):                         # unknown DFs: 56-bit reading reported
+        if rows.any():
+            crc = compute_crc(b[rows, :L - 24]) @ wts24
+            tail = b[rows, L - 24:L] @ wts24
+            syn[rows] = crc ^ tail
+    ok = np.isin(df, DF_PI) & (syn == 0)
+    flags = (df << DF_SHIFT) | np.where(is_long, FLAG_LONG, 0) | np.where(known, FLAG_KNOWN_DF, 0) | np.where(ok, FLAG_PARITY_OK, 0)
+    return dict(df=df, nbits=nbits, syndrome=syn, parity_ok=ok, flags=flags.astype(np.uint16))

@@ -61,3 +61,20 @@ def process_iq(iq, sps, thr, abs_offset=0, cap=None):
             cap = -r + 16
             continue
         return out[:r].copy()
+
+
+def parity_flags(recs):
+    """The Mode S parity pre-filter bits (oracle_mode_s_parity) for every demodulated record: returns
+    (flags_with_parity uint16[n], syndrome uint32[n]) -- what the device writes into adsb_burst.flags."""
+    c = ctypes
+    L = lib()
+    L.oracle_mode_s_parity.restype = c.c_uint32
+    flags = recs["flags"].astype(np.uint16).copy()
+    syn = np.zeros(len(recs), np.uint32)
+    bits = np.ascontiguousarray(recs["bits"])
+    f = c.c_uint(0)
+    for i in range(len(recs)):
+        if flags[i] & 1:
+            syn[i] = L.oracle_mode_s_parity(bits[i].ctypes.data_as(c.c_void_p), None, None, c.byref(f))
+            flags[i] |= f.value
+    return flags, syn

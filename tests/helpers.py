@@ -11,7 +11,7 @@ SCHEDULES = ("single", "fixed4096", "fixed8192", "random")
 
 
 def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "g*msps*.npz")))
 
 
 class Golden:
@@ -53,6 +53,22 @@ def assert_recs_match_golden(recs, g, s="single"):
     dem = (recs["flags"] & 1) != 0
     assert np.array_equal(recs["offset"][dem], g.get(s, "pdu_offsets")), "PDU set differs"
     assert np.array_equal(unpack(recs["bits"][dem]), g.pdu_bits(s)), "PDU bits differ"
+    if np.any(recs["flags"] & PARITY_BITS):
+        assert_parity_flags(recs, g.name)
+
+
+PARITY_BITS = 0x1FE0      # ADSB_BURST_PARITY_OK | _LONG | _KNOWN_DF | DF << 8
+
+
+def assert_parity_flags(recs, what=""):
+    """The Mode S pre-filter bits of device records equal the oracle's restatement of decoder.py:550-688
+    applied to the records' own bits (and are absent on records without a PDU)."""
+    from oracle import adsb_oracle as O
+    dem = (recs["flags"] & 1) != 0
+    assert not np.any(recs["flags"][~dem] & PARITY_BITS), what + ": parity bits on a record without PDU"
+    if dem.any():
+        want = O.mode_s_parity(unpack(recs["bits"][dem]))["flags"]
+        assert np.array_equal(recs["flags"][dem] & PARITY_BITS, want), what + ": parity pre-filter flags"
 
 
 def assert_recs_equal(a, b, what=""):
@@ -63,3 +79,6 @@ def assert_recs_equal(a, b, what=""):
     assert np.array_equal(a["median"].view(np.uint32), b["median"].view(np.uint32)), what + ": median"
     assert np.array_equal(a["flags"] & 1, b["flags"] & 1), what + ": demod flags"
     assert np.array_equal(a["bits"], b["bits"]), what + ": bits"
+    for r in (a, b):                       # device-produced side(s): the oracle's framer records carry no parity bits
+        if np.any(r["flags"] & PARITY_BITS):
+            assert_parity_flags(r, what)

@@ -83,6 +83,20 @@ def test_snr_db_c_close_to_numpy(native):
     assert ulp.max() <= 4
 
 
+def test_mode_s_syndrome_helper_matches_reference_known_answers(native):
+    """adsb_mode_s_syndrome (pure host arithmetic) against the reference decoder's known answers in
+    tests/golden/g_parity.npz: DF, payload length, pass/fail for DF 11/17/18/19, announced address otherwise."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g_parity.npz"))
+    for i in range(len(z["bits"])):
+        syn, df, nb = native.mode_s_syndrome(z["bits"][i])
+        assert df == z["df"][i] and (nb if nb else -1) == z["payload_length"][i]
+        if df in (11, 17, 18, 19):
+            assert (syn == 0) == bool(z["parity_passed"][i])
+        elif nb:
+            assert syn == z["aa"][i] and z["parity_passed"][i] == 0
+
+
 def test_stitch_is_the_reference_gate(native):
     from oracle import adsb_oracle as O
     rng = np.random.default_rng(1)

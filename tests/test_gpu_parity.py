@@ -177,6 +177,43 @@ def test_mixed_df_low_snr_config(native, torch_mod):
     assert_recs_equal(got, C.process_iq(iq, 2, 0.01), "mixed")
 
 
+def test_parity_prefilter_flags_and_block_option(native):
+    """the DF / length class / parity verdict attached to every PDU on the device equals the
+    oracle's restatement of decoder.py:550-688 (pinned to the reference decoder by tests/golden/g_parity.npz);
+    the demod block's opt-in filter drops exactly the PDUs check_parity() rejects without an aircraft table."""
+    from gr_adsb_amd import blocks, grshim
+    from gr_adsb_amd import modulator as M
+    from oracle import adsb_oracle as O
+    from oracle import c_oracle as C
+    dfs = (0, 4, 5, 11, 16, 17, 18, 19, 20, 21, 24, 7, 28)
+    for fs in (2e6, 8e6):
+        sps = int(fs // 1e6)
+        iq = M.synth_iq(1 << 21, fs, 4000, seed=78, df_choices=dfs, df_weights=[1.0 / len(dfs)] * len(dfs))
+        ctx = native.Context(fs, 0.01)
+        got = ctx.process_iq(iq)
+        want = C.process_iq(iq, sps, 0.01)
+        assert_recs_equal(got, want, "parity stream")
+        wf, wsyn = C.parity_flags(want)
+        assert np.array_equal(got["flags"] & 0x1FE1, wf & 0x1FE1)
+        assert len(np.unique(native.burst_df(got))) >= 10 and 50 < native.parity_ok(got).sum() < len(got)
+        for i in np.flatnonzero((got["flags"] & 1) != 0)[:200]:
+            syn, df, nb = native.mode_s_syndrome(got["bits"][i])
+            assert syn == wsyn[i] and df == native.burst_df(got)[i]
+        # the stand-alone demod block reports the same verdicts through ok[]
+        dem = (got["flags"] & 1) != 0
+        x = M.mag2(iq)
+        bits, ok, _ = ctx.demod_work(x, 0, got["offset"][dem])
+        assert ok.all() and np.array_equal(ctx.last_demod_flags, (got["flags"][dem] & 0xE1).astype(np.uint8))
+        # block option: publish only what can still pass check_parity()
+        fr, dm = blocks.framer(fs, 0.01), blocks.demod(fs, parity_filter=True)
+        dm.start_timestamp = 0.0
+        tags, msgs = grshim.drive(fr, dm, x, None)
+        p = O.mode_s_parity(unpack(got["bits"][dem]))
+        keep = (p["nbits"] != 0) & (~np.isin(p["df"], O.DF_PI) | p["parity_ok"])
+        offs = np.array([int(round(m[0]["timestamp"] * fs)) for _, m in msgs], dtype=np.int64)
+        assert np.array_equal(offs, got["offset"][dem][keep]) and dm.filtered == int((~keep).sum()) > 0
+
+
 def test_pathological_inputs(native):
     from gr_adsb_amd import modulator as M
     from oracle import adsb_oracle as O

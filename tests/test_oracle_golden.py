@@ -1,9 +1,11 @@
 """The oracle (NumPy and C) against the golden vectors generated from the REAL reference
 (tools/make_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
-from helpers import SCHEDULES, Golden, golden_names, snr_bits, unpack
+from helpers import GOLDEN_DIR, SCHEDULES, Golden, golden_names, snr_bits, unpack
 from oracle import adsb_oracle as O
 from oracle import c_oracle as C
 
@@ -55,3 +57,22 @@ def test_mag2_is_two_rounded_products():
     im = z.imag.astype(np.float64)
     want = (np.float32(re * re).astype(np.float64) + np.float32(im * im).astype(np.float64)).astype(np.float32)
     assert np.array_equal(O.mag2(z), want)
+
+
+def test_parity_oracle_matches_reference_decoder_known_answers():
+    """tests/golden/g_parity.npz (tools/make_golden_parity.py): DF, payload length, check_parity() verdict
+    and announced address of the reference decoder (decoder.py:550-688) for 1028 PDUs, vs both oracles."""
+    from oracle import c_oracle as C
+    z = np.load(os.path.join(GOLDEN_DIR, "g_parity.npz"))
+    bits = np.unpackbits(z["bits"], axis=1)[:, :112]
+    p = O.mode_s_parity(bits)
+    assert np.array_equal(p["df"], z["df"])
+    assert np.array_equal(np.where(p["nbits"] == 0, -1, p["nbits"]), z["payload_length"])
+    assert np.array_equal(p["parity_ok"].astype(np.int32), z["parity_passed"])     # empty aircraft table
+    ap = np.isin(z["df"], (0, 4, 5, 16, 20, 21, 24))
+    assert ap.sum() > 100 and p["parity_ok"].sum() > 100
+    assert np.array_equal(p["syndrome"][ap], z["aa"][ap])
+    recs = np.zeros(len(bits), dtype=C.REC)
+    recs["bits"] = z["bits"]; recs["flags"] = 1
+    cf, csyn = C.parity_flags(recs)
+    assert np.array_equal(cf & 0x1FE0, p["flags"]) and np.array_equal(csyn.astype(np.int64), p["syndrome"])

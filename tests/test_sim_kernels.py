@@ -157,3 +157,27 @@ def test_gated_shards_with_head_fixup_equal_single_call(fs, bps, shards, head):
         assert not np.any(k["flags"] & 16) and np.all(k["flags"] & 2)
         outs.append(k)
     assert_recs_equal(np.concatenate(outs), want, "gated shards + fixup")
+
+
+@pytest.mark.parametrize("fs,mode", [(2e6, 0), (4e6, 1), (8e6, 2)])
+def test_parity_prefilter_flags_all_formats(fs, mode):
+    """DF / length class / parity verdict the device attaches to every PDU equal the oracle's
+    restatement of decoder.py:550-688 (pinned against the reference decoder), for every downlink format."""
+    dfs = (0, 4, 5, 11, 16, 17, 18, 19, 20, 21, 24, 7, 28)
+    iq = M.synth_iq(1 << 18, fs, 5000, seed=77, df_choices=dfs, df_weights=[1.0 / len(dfs)] * len(dfs))
+    if mode == 2:
+        q = M.quantize_iq16(iq)
+        scale = float(np.float32(2.0 / 32767.0))
+        data, x = q, O.mag2_iq16(q, scale)
+        recs, _ = simlib.sim_canonical(2, q, fs, 0.01, scale=scale)
+    else:
+        x = M.mag2(iq)
+        recs, _ = simlib.sim_canonical(mode, iq if mode == 0 else x, fs, 0.01)
+    want = C.canonical(x, int(fs // 1e6), np.float32(0.01))
+    assert_recs_equal(recs, want, "parity stream")
+    wf, _ = C.parity_flags(want)
+    assert np.array_equal(recs["flags"] & 0x1FE1, wf & 0x1FE1)
+    df = (recs["flags"] >> 8) & 31
+    ok = (recs["flags"] & 32) != 0
+    assert len(np.unique(df)) >= 10 and 10 < ok.sum() < len(recs)
+    assert set(np.unique(df[ok])) <= {11, 17, 18, 19}

@@ -95,8 +95,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-log2n", type=int, default=26, help="log2 of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--format", choices=["fc32", "sc16"], default="fc32",
-                    help="input sample format: complex64 (BASELINE workload) or int16 IQ (4 B/sample; N=1 only)")
+    ap.add_argument("--format", choices=["fc32", "sc16", "sc8", "cu8"], default="fc32",
+                    help="input sample format: complex64 (BASELINE workload), int16 IQ (4 B/sample) or 8-bit IQ "
+                         "(2 B/sample: int8 / RTL-SDR offset binary); integer formats N=1 only")
     args = ap.parse_args()
 
     import torch
@@ -126,14 +127,22 @@ def main():
     stream_len = n_own * n_gpus
     fe = FrontEnd(fs, args.threshold, device=local_rank, timing=True)
 
-    sc16 = args.format == "sc16"
+    sc16 = args.format != "fc32"            # any integer wire format (name kept from the first one added)
+    fmt = {"fc32": _native.FMT_FC32, "sc16": _native.FMT_SC16, "sc8": _native.FMT_SC8, "cu8": _native.FMT_CU8}[args.format]
     assert not (sc16 and n_gpus > 1)
     if n_gpus == 1:
         iq = gen_stream_blocks(n_own, 0, fs, args.bursts, args.seed, dev)
         plan = None
-        if sc16:   # quantise the same stream to int16 (full scale 4.0); the kernel converts with the same scale
-            fe.ctx.set_iq16_scale(4.0 / 32767.0)
+        # quantise the same stream to the integer wire format (full scale 4.0); the kernel converts with the same scale
+        if fmt == _native.FMT_SC16:
+            fe.ctx.set_format_scale(fmt, 4.0 / 32767.0)
             iq = torch.clamp(torch.round(iq * (32767.0 / 4.0)), -32768, 32767).to(torch.int16).contiguous()
+        elif fmt == _native.FMT_SC8:
+            fe.ctx.set_format_scale(fmt, 4.0 / 127.0)
+            iq = torch.clamp(torch.round(iq * (127.0 / 4.0)), -128, 127).to(torch.int8).contiguous()
+        elif fmt == _native.FMT_CU8:
+            fe.ctx.set_format_scale(fmt, 4.0 / 255.0)
+            iq = torch.clamp(torch.floor(iq * (127.5 / 4.0) + 128.0), 0, 255).to(torch.uint8).contiguous()
     else:
         plan = shard_plan(stream_len, n_gpus, sps, align=n_own)[rank]
         iq = gen_stream_blocks(plan["hi"] - plan["lo"], plan["lo"], fs, args.bursts, args.seed, dev)
@@ -146,7 +155,7 @@ def main():
         if n_gpus == 1:
             # submit pass i+1 before collecting pass i: the PCIe copy and host work of one pass overlap the
             # kernels of the next; every pass is collected inside the timed region (drain() below)
-            pending.append(fe.submit_iq16_tensor(iq, 0) if sc16 else fe.submit_iq_tensor(iq, 0))
+            pending.append(fe.submit_format_tensor(fmt, iq, 0))
             if len(pending) == DEPTH:
                 return fe.wait(pending.pop(0), fetch=False)
             return 0
@@ -219,7 +228,7 @@ def main():
     if n_gpus == 1:
         fe.ctx.reset_stats()
         for _ in range(5):
-            (fe.ctx.process_iq16_device if sc16 else fe.ctx.process_iq_device)(iq.data_ptr(), n_own, 0, fetch=False)
+            fe.ctx.process_format_device(fmt, iq.data_ptr(), n_own, 0, fetch=False)
         st_iso = fe.stats()
         iso_ms = st_iso["detect_ms"] / max(1, st_iso["detect_launches"])
 
@@ -241,12 +250,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.format == "fc32" else "i16->f32",
+            "dtype": "f32" if args.format == "fc32" else {"sc16": "i16->f32", "sc8": "i8->f32", "cu8": "u8->f32"}[args.format],
             "data": "synthetic",
             "config": {
                 "workload": "synthetic %g Msps %s IQ, %g DF17-length bursts/s, AWGN 1e-3, threshold %g; "
                             "2^%d samples per GPU per step resident in HBM; one canonical framer+demod pass"
-                            % (fs / 1e6, "int16" if sc16 else "complex64", args.bursts, args.threshold, args.log2n),
+                            % (fs / 1e6, {"fc32": "complex64", "sc16": "int16", "sc8": "int8", "cu8": "uint8 offset-binary"}[args.format], args.bursts, args.threshold, args.log2n),
                 "fs": fs, "samples_per_gpu_per_step": n_own, "bursts_per_step_rank0": int(n_bursts),
                 "sharding": "none" if n_gpus == 1 else "%d overlapped time shards, host stitch" % n_gpus,
                 "pipeline": "%d passes in flight (submit/wait)" % DEPTH,
@@ -254,11 +263,11 @@ def main():
                 "detect_grid": int(st["detect_grid"]), "retries": int(st["retries"]), "longrun_calls": int(st["longrun_calls"]),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_detect<%s>" % ("int16 IQ" if sc16 else "complex64"),
+                "bound": "hbm", "kernel": "k_detect<%s>" % args.format,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
-                "kernel_only_msamples_per_s": round(alg_bytes / 8 / (kern_ms * 1e-3) / 1e6, 1) if kern_ms > 0 else 0.0,
+                "kernel_only_msamples_per_s": round(st["detect_samples"] / max(1, st["detect_launches"]) / (kern_ms * 1e-3) / 1e6, 1) if kern_ms > 0 else 0.0,
                 "isolated": None if iso_ms is None else {
                     "kernel_ms": round(iso_ms, 4), "achieved": round(alg_bytes / (iso_ms * 1e-3) / 1e9, 1),
                     "frac": round(alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

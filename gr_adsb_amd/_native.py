@@ -15,6 +15,11 @@ BURST_DTYPE = np.dtype([("offset", "<i8"), ("peak", "<f4"), ("median", "<f4"), (
 assert BURST_DTYPE.itemsize == 32
 
 FLAG_TIMING = 1
+# input sample formats (include/adsb_hip.h ADSB_FMT_*): numpy dtype of the flat host array, items per sample
+FMT_FC32, FMT_MAG2, FMT_SC16, FMT_SC8, FMT_CU8 = 0, 1, 2, 3, 4
+FMT_LAYOUT = {FMT_FC32: (np.complex64, 1), FMT_MAG2: (np.float32, 1), FMT_SC16: (np.int16, 2), FMT_SC8: (np.int8, 2),
+              FMT_CU8: (np.uint8, 2)}
+FMT_BYTES = {FMT_FC32: 8, FMT_MAG2: 4, FMT_SC16: 4, FMT_SC8: 2, FMT_CU8: 2}
 BURST_DEMOD = 1
 BURST_KEPT = 2
 BURST_PARITY_OK = 32     # Mode S parity pre-filter bits (include/adsb_hip.h; decoder.py:550-688)
@@ -28,6 +33,7 @@ EXPORTS = [
     "adsb_process_iq", "adsb_process_mag2", "adsb_process_iq_device", "adsb_process_mag2_device", "adsb_last_result",
     "adsb_submit_iq_device", "adsb_submit_mag2_device", "adsb_submit_iq16_device", "adsb_submit_shard_device", "adsb_wait",
     "adsb_set_iq16_scale", "adsb_process_iq16", "adsb_process_iq16_device",
+    "adsb_set_format_scale", "adsb_process_format", "adsb_process_format_device", "adsb_submit_format_device",
     "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_mode_s_syndrome", "adsb_get_stats",
     "adsb_reset_stats", "adsb_last_error", "adsb_host_alloc", "adsb_host_free",
 ]
@@ -82,6 +88,10 @@ def load():
     for name in ("adsb_process_iq", "adsb_process_mag2", "adsb_process_iq_device", "adsb_process_mag2_device",
                  "adsb_process_iq16", "adsb_process_iq16_device"):
         getattr(lib, name).argtypes = [vp, vp, i64, i64, vp, i32, c.POINTER(i32)]
+    lib.adsb_set_format_scale.argtypes = [vp, c.c_int, f32]
+    lib.adsb_process_format.argtypes = [vp, c.c_int, vp, i64, i64, vp, i32, c.POINTER(i32)]
+    lib.adsb_process_format_device.argtypes = [vp, c.c_int, vp, i64, i64, vp, i32, c.POINTER(i32)]
+    lib.adsb_submit_format_device.argtypes = [vp, c.c_int, vp, i64, i64, c.POINTER(i32)]
     lib.adsb_last_result.argtypes = [vp, c.POINTER(vp), c.POINTER(i32)]
     lib.adsb_submit_iq_device.argtypes = [vp, vp, i64, i64, c.POINTER(i32)]
     lib.adsb_submit_mag2_device.argtypes = [vp, vp, i64, i64, c.POINTER(i32)]
@@ -167,6 +177,30 @@ class Context:
     def process_mag2(self, x, abs_offset=0):
         x = np.ascontiguousarray(x, dtype=np.float32)
         return self._run(self.lib.adsb_process_mag2, x.ctypes.data, len(x), abs_offset)
+
+    def set_format_scale(self, fmt, scale):
+        self._chk(self.lib.adsb_set_format_scale(self._h, int(fmt), float(np.float32(scale))))
+
+    def process_format(self, fmt, data, abs_offset=0):
+        """Host array in any ADSB_FMT_* layout (integer IQ: flat interleaved I,Q array of 2n items)."""
+        dt, per = FMT_LAYOUT[int(fmt)]
+        data = np.ascontiguousarray(data, dtype=dt)
+        n_out = ctypes.c_int32(0)
+        self._chk(self.lib.adsb_process_format(self._h, int(fmt), ctypes.c_void_p(data.ctypes.data), len(data) // per,
+                                               int(abs_offset), None, 0, ctypes.byref(n_out)))
+        return self.last_result()
+
+    def process_format_device(self, fmt, dev_ptr, n, abs_offset=0, fetch=True):
+        n_out = ctypes.c_int32(0)
+        self._chk(self.lib.adsb_process_format_device(self._h, int(fmt), ctypes.c_void_p(int(dev_ptr)), int(n), int(abs_offset),
+                                                      None, 0, ctypes.byref(n_out)))
+        return self.last_result() if fetch else n_out.value
+
+    def submit_format_device(self, fmt, dev_ptr, n, abs_offset=0):
+        t = ctypes.c_int32(-1)
+        self._chk(self.lib.adsb_submit_format_device(self._h, int(fmt), ctypes.c_void_p(int(dev_ptr)), int(n), int(abs_offset),
+                                                     ctypes.byref(t)))
+        return t.value
 
     def set_iq16_scale(self, scale):
         self._chk(self.lib.adsb_set_iq16_scale(self._h, float(np.float32(scale))))

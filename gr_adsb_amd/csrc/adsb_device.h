@@ -117,7 +117,7 @@ struct Summary {
 };
 
 struct DetectArgs {
-  const void* data;      // MODE 0: float2[n] complex64 IQ; MODE 1: float[n] |IQ|^2; MODE 2: short2[n] int16 IQ
+  const void* data;      // MODE 0: float2[n] complex64 IQ; 1: float[n] |IQ|^2; 2: short2[n] int16 IQ; 3: char2[n] int8 IQ; 4: uchar2[n] offset-binary IQ
   long long n;           // samples present; x(i) = 0 for i < 0 or i >= n
   long long in0_base;    // local index of the framer's in0[0] (-(8*sps-1) on a fresh stream)
   long long scan_lo;     // rises (and falls) are owned / counted in [scan_lo, scan_hi)
@@ -128,7 +128,7 @@ struct DetectArgs {
   long long chunk;       // samples per unit (= wavefront), multiple of kWTile
   float thr;
   float prev_in0;        // value compared for the sample before in0[0] (framer.py:84)
-  float scale;           // MODE 2: float32 multiplier applied to every int16 component
+  float scale;           // MODE 2/3/4: float32 multiplier applied to every integer component
   int sps;
   int end_is_call_end;   // 1: pulse still high at fall_hi is discarded (framer.py:102-108); 0: halo error
   int rec_cap;           // centres per unit
@@ -154,6 +154,20 @@ __device__ __forceinline__ float mag2_iq16(unsigned iq, float scale) {
   return mag2f(re, im);
 }
 
+// 8-bit IQ (I in the low byte): MODE 3 = two's complement (cs8: HackRF, SDRplay): component = f32(int8) * scale;
+// MODE 4 = offset binary (cu8: RTL-SDR): component = f32(2*u8 - 255) * scale, i.e. (u8 - 127.5) * 2*scale with
+// the subtraction done exactly in integers.  One rounded multiply per component, then |.|^2 as above.
+template <int MODE>
+__device__ __forceinline__ float mag2_iq8(unsigned iq, float scale) {
+  int i8 = (int)(iq & 0xFFu), q8 = (int)((iq >> 8) & 0xFFu);
+  if (MODE == 3) { i8 = (int)(signed char)i8; q8 = (int)(signed char)q8; }
+  else { i8 = 2 * i8 - 255; q8 = 2 * q8 - 255; }
+  return mag2f(__fmul_rn((float)i8, scale), __fmul_rn((float)q8, scale));
+}
+
+constexpr bool mode_is_iq8(int mode) { return mode == 3 || mode == 4; }
+constexpr int mode_bytes(int mode) { return mode == 0 ? 8 : mode_is_iq8(mode) ? 2 : 4; }   // bytes per sample
+
 template <int MODE>
 __device__ __forceinline__ float load_sample(const void* data, long long i, float scale) {
   if (MODE == 0) {
@@ -161,6 +175,7 @@ __device__ __forceinline__ float load_sample(const void* data, long long i, floa
     return mag2f(q.x, q.y);
   }
   if (MODE == 2) return mag2_iq16(reinterpret_cast<const unsigned*>(data)[i], scale);
+  if (mode_is_iq8(MODE)) return mag2_iq8<MODE>(reinterpret_cast<const unsigned short*>(data)[i], scale);
   return reinterpret_cast<const float*>(data)[i];
 }
 
@@ -309,14 +324,16 @@ __device__ void emit_record(const DetectArgs& a, long long p, unsigned xflags, R
 // into |IQ|^2 floats in LDS AND into the natural-order threshold bitmask words of those samples
 // (span_commit) -- so the fetch of tile k+1 is in flight while tile k is processed, and the threshold
 // masks cost no LDS re-read.  The fast path (whole span inside the buffer) has no per-load branches.
+template <bool IQ8> struct SelectQ { using type = float4; };
+template <> struct SelectQ<true> { using type = float2; };
 template <int MODE, int COUNT, int NWAVES = kWaves>
 struct Span {
-  static constexpr int PER = (MODE == 0) ? 2 : 4;             // samples per 16-byte load (complex64: 2; float / int16 IQ: 4)
+  static constexpr int PER = (MODE == 0) ? 2 : 4;             // samples per lane load (complex64: 2 in 16 B; float / int16 IQ: 4 in 16 B; int8 IQ: 4 in 8 B)
   static constexpr int SHARE = COUNT / NWAVES;                // samples per wavefront (NWAVES share the span)
   static constexpr int GROUP = 64 * PER;                      // samples per wave-wide load
   static constexpr int ITER = (SHARE + GROUP - 1) / GROUP;    // (a partial last group only for the head span)
   static constexpr int LANES = (SHARE < GROUP) ? SHARE / PER : 64;   // active lanes when SHARE < GROUP
-  using Q = float4;
+  using Q = typename SelectQ<mode_is_iq8(MODE)>::type;
   Q q[ITER];
 };
 
@@ -328,7 +345,7 @@ __device__ __forceinline__ bool span_issue(Span<MODE, COUNT, NWAVES>& sp, const 
   if (src + COUNT > a.n) return false;
   // scalar base + 32-bit lane offset: one address VGPR for all loads of the span
   const long long wsrc = src + (long long)wave * S::SHARE;
-  constexpr int BPS = (MODE == 0) ? 8 : 4;                    // bytes per sample
+  constexpr int BPS = mode_bytes(MODE);                       // bytes per sample
   const char* ub = reinterpret_cast<const char*>(a.data) + wsrc * BPS;
   using Q = typename S::Q;
   const unsigned lo = (unsigned)lane * (unsigned)sizeof(Q);
@@ -385,12 +402,20 @@ __device__ __forceinline__ void span_commit(const Span<MODE, COUNT, NWAVES>& sp,
         }
       }
     } else {
-      float4 m = sp.q[k];
-      if (MODE == 2) {                                        // 8 int16 -> 4 |IQ|^2
+      float4 m;
+      if constexpr (mode_is_iq8(MODE)) {                      // 8 int8 -> 4 |IQ|^2
+        const unsigned u0 = __builtin_bit_cast(unsigned, sp.q[k].x), u1 = __builtin_bit_cast(unsigned, sp.q[k].y);
+        m.x = mag2_iq8<MODE>(u0 & 0xFFFFu, scale);
+        m.y = mag2_iq8<MODE>(u0 >> 16, scale);
+        m.z = mag2_iq8<MODE>(u1 & 0xFFFFu, scale);
+        m.w = mag2_iq8<MODE>(u1 >> 16, scale);
+      } else if constexpr (MODE == 2) {                       // 8 int16 -> 4 |IQ|^2
         m.x = mag2_iq16(__builtin_bit_cast(unsigned, sp.q[k].x), scale);
         m.y = mag2_iq16(__builtin_bit_cast(unsigned, sp.q[k].y), scale);
         m.z = mag2_iq16(__builtin_bit_cast(unsigned, sp.q[k].z), scale);
         m.w = mag2_iq16(__builtin_bit_cast(unsigned, sp.q[k].w), scale);
+      } else {
+        m = sp.q[k];
       }
       if (act) *reinterpret_cast<float4*>(&sx[g + 4 * lane]) = m;
       if (!kNoMasks) {

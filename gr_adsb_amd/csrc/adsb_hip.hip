@@ -84,8 +84,9 @@ struct adsb_ctx {
   bool split_tail = false;
   bool own_stream = false;
   int n_cu = 256;
-  int bpc[3] = {4, 4, 4};  // resident k_detect workgroups per CU (occupancy query), per input mode
-  float scale16 = 1.0f / 32768.0f;  // int16 IQ component -> float32 multiplier (adsb_set_iq16_scale)
+  int bpc[ADSB_FMT_COUNT] = {4, 4, 4, 4, 4};  // resident k_detect workgroups per CU (occupancy query), per input format
+  // integer IQ component -> float32 multiplier per format (adsb_set_format_scale); unused for the float formats
+  float scale[ADSB_FMT_COUNT] = {1.0f, 1.0f, 1.0f / 32768.0f, 1.0f / 128.0f, 1.0f / 255.0f};
   FramerState st;       // framer.py:54,57
   Slot slot[ADSB_MAX_IN_FLIGHT];
   int next_slot = 0;
@@ -132,6 +133,16 @@ int ensure_pinned(adsb_ctx* c, void*& p, size_t& cap, size_t bytes) {
   return 0;
 }
 
+// one instantiation of every sample-reading kernel per input format (ADSB_FMT_*)
+#define ADSB_BY_MODE(mode, F, ...)            \
+  switch (mode) {                             \
+    case 0: F<0>(__VA_ARGS__); break;         \
+    case 1: F<1>(__VA_ARGS__); break;         \
+    case 2: F<2>(__VA_ARGS__); break;         \
+    case 3: F<3>(__VA_ARGS__); break;         \
+    default: F<4>(__VA_ARGS__); break;        \
+  }
+
 template <int MODE>
 void launch_detect(adsb_ctx* c, const DetectArgs& a, int grid) {
   // ADSB_DEBUG_DYNLDS (bytes): tuning knob that pads the workgroup's LDS to lower occupancy on purpose
@@ -169,7 +180,7 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
     ts = c->tail_stream;
   }
   // no-op unless k_detect listed pulses longer than its LDS window
-  if (pl.mode == 0) launch_longrun<0>(ts, a); else if (pl.mode == 1) launch_longrun<1>(ts, a); else launch_longrun<2>(ts, a);
+  ADSB_BY_MODE(pl.mode, launch_longrun, ts, a);
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(kThreads), 0, ts, (const int*)a.blk_count,
                      (const long long*)a.blk_lastp, (const unsigned*)a.blk_flags, s.nlists, s.rec_cap,
                      (const int*)a.long_count, (const unsigned long long*)a.long_lastp, (int*)s.d_blk_off.p, &misc->sum);
@@ -190,9 +201,7 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kThreads), 0, ts, (int*)s.d_seg.p, &misc->sum, a.long_count, a.long_lastp);
   hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted, &misc->sum,
                      (const int*)s.d_seg.p, fmask, fwant, pl.head_n, kept, (int)s.tot);
-  if (pl.mode == 0) launch_burst<0>(c, ts, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
-  else if (pl.mode == 1) launch_burst<1>(c, ts, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
-  else launch_burst<2>(c, ts, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
+  ADSB_BY_MODE(pl.mode, launch_burst, c, ts, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
   HIPCHK(c, hipMemcpyAsync(s.h_sum, &misc->sum, sizeof(Summary), hipMemcpyDeviceToHost, ts));
   HIPCHK(c, hipEventRecord(s.done, ts));
   return 0;
@@ -241,14 +250,14 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   DetectArgs& a = s.args;
   a.data = pl.d_data; a.n = pl.n; a.in0_base = pl.in0_base; a.scan_lo = pl.scan_lo; a.scan_hi = pl.scan_hi;
   a.fall_hi = pl.fall_hi; a.dem_hi = pl.dem_hi; a.origin = pl.origin; a.chunk = chunk; a.thr = c->thr;
-  a.prev_in0 = pl.prev_in0; a.scale = c->scale16; a.sps = c->sps; a.end_is_call_end = pl.end_is_call_end; a.rec_cap = s.rec_cap;
+  a.prev_in0 = pl.prev_in0; a.scale = c->scale[pl.mode]; a.sps = c->sps; a.end_is_call_end = pl.end_is_call_end; a.rec_cap = s.rec_cap;
   a.long_cap = (int)long_cap; a.cands = (unsigned long long*)s.d_cands.p; a.blk_count = (int*)s.d_blk_count.p;
   a.blk_lastp = (long long*)s.d_blk_lastp.p; a.blk_flags = (unsigned*)s.d_blk_flags.p;
   a.longlist = (LongRise*)s.d_long.p; a.long_count = &misc->long_count; a.long_lastp = &misc->long_lastp;
 
   const bool timing = (c->flags & ADSB_FLAG_TIMING) != 0;
   if (timing) HIPCHK(c, hipEventRecord(s.ev0, c->stream));
-  if (pl.mode == 0) launch_detect<0>(c, a, grid); else if (pl.mode == 1) launch_detect<1>(c, a, grid); else launch_detect<2>(c, a, grid);
+  ADSB_BY_MODE(pl.mode, launch_detect, c, a, grid);
   if (timing) HIPCHK(c, hipEventRecord(s.ev1, c->stream));
   c->stats.detect_grid = (uint64_t)grid; c->stats.blocks_per_cu = (uint64_t)c->bpc[pl.mode];
   c->stats.calls++;
@@ -282,7 +291,7 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
         } else (void)hipGetLastError();
       }
       c->stats.detect_samples += (uint64_t)s.span;
-      c->stats.detect_bytes += (uint64_t)s.span * (s.plan.mode == 0 ? 8u : 4u);
+      c->stats.detect_bytes += (uint64_t)s.span * (uint64_t)mode_bytes(s.plan.mode);
     }
     if (s.h_sum->overflow) {
       if ((long long)s.rec_cap >= s.chunk / 2 + 8) { s.busy = false; return fail(c, -EIO, "centre list overflow at maximum size"); }
@@ -415,6 +424,8 @@ int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx
     if ((nb = detect_occupancy<0>()) > 0) c->bpc[0] = nb;
     if ((nb = detect_occupancy<1>()) > 0) c->bpc[1] = nb;
     if ((nb = detect_occupancy<2>()) > 0) c->bpc[2] = nb;
+    if ((nb = detect_occupancy<3>()) > 0) c->bpc[3] = nb;
+    if ((nb = detect_occupancy<4>()) > 0) c->bpc[4] = nb;
   }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return -EIO; }
   c->own_stream = true;
@@ -483,10 +494,29 @@ int adsb_process_iq_device(adsb_ctx* c, const void* d_iq, int64_t n, int64_t abs
   return canonical(c, 0, d_iq, n, abs_offset, out, cap, n_out);
 }
 
-int adsb_set_iq16_scale(adsb_ctx* c, float scale) {
-  if (!c) return -EINVAL;
-  c->scale16 = scale;
+int adsb_set_iq16_scale(adsb_ctx* c, float scale) { return adsb_set_format_scale(c, ADSB_FMT_SC16, scale); }
+
+int adsb_set_format_scale(adsb_ctx* c, int format, float scale) {
+  if (!c || format < ADSB_FMT_SC16 || format >= ADSB_FMT_COUNT) return -EINVAL;
+  c->scale[format] = scale;
   return 0;
+}
+
+int adsb_process_format_device(adsb_ctx* c, int format, const void* d_data, int64_t n, int64_t abs_offset,
+                               adsb_burst* out, int32_t cap, int32_t* n_out) {
+  if (!c || format < 0 || format >= ADSB_FMT_COUNT) return -EINVAL;
+  return canonical(c, format, d_data, n, abs_offset, out, cap, n_out);
+}
+
+int adsb_process_format(adsb_ctx* c, int format, const void* host, int64_t n, int64_t abs_offset, adsb_burst* out,
+                        int32_t cap, int32_t* n_out) {
+  if (!c || format < 0 || format >= ADSB_FMT_COUNT || n < 0 || (n > 0 && !host)) return -EINVAL;
+  if (n == 0) { if (n_out) *n_out = 0; c->slot[c->last_slot].nres = 0; return 0; }
+  HIPCHK(c, hipSetDevice(c->device));
+  void* d = nullptr;
+  int rc = upload(c, host, (size_t)n * (size_t)mode_bytes(format), &d);
+  if (rc) return rc;
+  return canonical(c, format, d, n, abs_offset, out, cap, n_out);
 }
 
 int adsb_process_iq16_device(adsb_ctx* c, const void* d_iq16, int64_t n, int64_t abs_offset, adsb_burst* out,
@@ -546,6 +576,11 @@ static int submit_canonical(adsb_ctx* c, int mode, const void* d_data, int64_t n
   *ticket = c->next_slot;
   c->next_slot = (c->next_slot + 1) % ADSB_MAX_IN_FLIGHT;
   return 0;
+}
+
+int adsb_submit_format_device(adsb_ctx* c, int format, const void* d_data, int64_t n, int64_t abs_offset, int32_t* ticket) {
+  if (!c || format < 0 || format >= ADSB_FMT_COUNT) return -EINVAL;
+  return submit_canonical(c, format, d_data, n, abs_offset, ticket);
 }
 
 int adsb_submit_iq_device(adsb_ctx* c, const void* d_iq, int64_t n, int64_t abs_offset, int32_t* ticket) {
@@ -657,7 +692,7 @@ static int shard_post(adsb_ctx* c, Slot& s, const Summary& sum, int32_t nres) {
 
 static int shard_plan_checked(adsb_ctx* c, int fmt, const void* d_data, int64_t n, int64_t origin, int64_t own_lo,
                               int64_t own_hi, int64_t stream_len, int32_t head_cands, Plan* pl) {
-  if (!c || n < 0 || fmt < 0 || fmt > 2 || head_cands < 0) return -EINVAL;
+  if (!c || n < 0 || fmt < 0 || fmt >= ADSB_FMT_COUNT || head_cands < 0) return -EINVAL;
   if (((uintptr_t)d_data & 15u) != 0) return fail(c, -EINVAL, "device pointer must be 16-byte aligned");
   *pl = plan_shard(fmt, d_data, n, origin, own_lo, own_hi, stream_len, c->sps, head_cands);
   if (origin > 0 && pl->scan_lo < 1) return fail(c, -EINVAL, "shard needs at least one sample of back halo");

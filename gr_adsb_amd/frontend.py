@@ -54,7 +54,28 @@ class FrontEnd:
             self.ctx.set_iq16_scale(scale)
         return self.ctx.process_iq16(iq16, abs_offset)
 
+    def process_iq8(self, iq8, abs_offset=0, scale=None):
+        """iq8: interleaved 8-bit I,Q: int8 (cs8) or uint8 (cu8, offset binary around 127.5: RTL-SDR), chosen by
+        the array's dtype; scale: float32 multiplier per component (defaults 1/128 resp. 1/255 per half LSB)."""
+        iq8 = np.asarray(iq8)
+        fmt = _native.FMT_CU8 if iq8.dtype == np.uint8 else _native.FMT_SC8
+        if scale is not None:
+            self.ctx.set_format_scale(fmt, scale)
+        return self.ctx.process_format(fmt, iq8, abs_offset)
+
+    def process_format(self, fmt, data, abs_offset=0):
+        return self.ctx.process_format(fmt, data, abs_offset)
+
     # -- torch tensors already in HBM ---------------------------------------------------------------
+    def process_format_tensor(self, fmt, t, abs_offset=0, fetch=True):
+        """t: contiguous CUDA tensor whose first dimension is the sample count ([n,2] for the IQ formats)."""
+        assert t.is_cuda and t.is_contiguous()
+        return self.ctx.process_format_device(fmt, t.data_ptr(), t.shape[0], abs_offset, fetch=fetch)
+
+    def submit_format_tensor(self, fmt, t, abs_offset=0):
+        assert t.is_cuda and t.is_contiguous()
+        return self.ctx.submit_format_device(fmt, t.data_ptr(), t.shape[0], abs_offset)
+
     def process_iq_tensor(self, t, abs_offset=0, fetch=True):
         """t: float32 [n,2] (or complex64 [n]) CUDA tensor, contiguous."""
         assert t.is_cuda and t.is_contiguous()

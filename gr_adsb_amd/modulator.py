@@ -116,6 +116,16 @@ def quantize_iq16(iq, full_scale=2.0):
     return np.clip(np.rint(v * (32767.0 / full_scale)), -32768, 32767).astype(np.int16)
 
 
+def quantize_iq8(iq, full_scale=2.0, offset_binary=False):
+    """8-bit interleaved IQ: int8 (cs8) or, with offset_binary, uint8 around 127.5 (cu8, RTL-SDR)."""
+    v = np.empty(2 * len(iq), dtype=np.float32)
+    v[0::2] = iq.real
+    v[1::2] = iq.imag
+    if offset_binary:
+        return np.clip(np.floor(v * (127.5 / full_scale) + 128.0), 0, 255).astype(np.uint8)
+    return np.clip(np.rint(v * (127.0 / full_scale)), -128, 127).astype(np.int8)
+
+
 def dequantize_iq16(q, full_scale=2.0):
     v = q.astype(np.float32) * np.float32(full_scale / 32767.0)
     return (v[0::2] + 1j * v[1::2]).astype(np.complex64)

@@ -34,6 +34,17 @@ extern "C" {
 #define ADSB_ABI_VERSION 1
 #define ADSB_MAX_IN_FLIGHT 3 /* adsb_submit_* calls that may be pending at once */
 
+/* Input sample formats (the `format` / `fmt` argument).  The reference's flowgraph feeds complex64 from the
+ * SDR source through complex_to_mag_squared (examples/adsb_rx.py:116,180); the integer formats are the same
+ * samples as the SDR hardware delivers them, converted exactly on the device. */
+#define ADSB_FMT_FC32 0 /* interleaved float32 I,Q           8 B/sample */
+#define ADSB_FMT_MAG2 1 /* float32 |IQ|^2 (the framer's own input type, framer.py:38)  4 B/sample */
+#define ADSB_FMT_SC16 2 /* interleaved int16 I,Q             4 B/sample   component = f32(i16) * scale   (default 1/32768) */
+#define ADSB_FMT_SC8 3  /* interleaved int8 I,Q              2 B/sample   component = f32(i8) * scale    (default 1/128) */
+#define ADSB_FMT_CU8 4  /* interleaved uint8 I,Q, offset binary (RTL-SDR)  2 B/sample
+                         * component = f32(2*u8 - 255) * scale, i.e. (u8 - 127.5) * 2*scale, exact (default 1/255) */
+#define ADSB_FMT_COUNT 5
+
 /* adsb_create flags */
 #define ADSB_FLAG_TIMING 1u /* bracket the detect kernel with HIP events (adsb_get_stats) */
 
@@ -67,7 +78,7 @@ typedef struct adsb_stats {
   uint64_t detect_launches;  /* k_detect launches timed */
   double detect_ms;          /* sum of their HIP-event durations */
   uint64_t detect_samples;   /* samples those launches covered */
-  uint64_t detect_bytes;     /* algorithmic bytes: 8 B (complex64) or 4 B (float |IQ|^2, int16 IQ) per sample */
+  uint64_t detect_bytes;     /* algorithmic bytes: samples x the format's bytes per sample */
   uint64_t calls;
   uint64_t retries;          /* record-capacity regrowths */
   uint64_t longrun_calls;    /* calls that needed the long-pulse kernel */
@@ -118,6 +129,15 @@ int adsb_process_iq16(adsb_ctx* ctx, const int16_t* iq16_host, int64_t n, int64_
                       adsb_burst* out, int32_t cap, int32_t* n_out);
 int adsb_process_iq16_device(adsb_ctx* ctx, const void* d_iq16, int64_t n, int64_t abs_offset,
                              adsb_burst* out, int32_t cap, int32_t* n_out);
+/* Any format by number (ADSB_FMT_*): the entry points above are adsb_process_format[_device] with format 0, 1, 2.
+ * Integer components become float32 exactly and are multiplied by the format's scale (one rounded float32
+ * multiply) before |IQ|^2 = re*re + im*im with separately rounded products; downstream is identical.
+ * adsb_set_format_scale: format must be one of the integer formats (-EINVAL otherwise). */
+int adsb_set_format_scale(adsb_ctx* ctx, int format, float scale);
+int adsb_process_format(adsb_ctx* ctx, int format, const void* host, int64_t n, int64_t abs_offset,
+                        adsb_burst* out, int32_t cap, int32_t* n_out);
+int adsb_process_format_device(adsb_ctx* ctx, int format, const void* d_data, int64_t n, int64_t abs_offset,
+                               adsb_burst* out, int32_t cap, int32_t* n_out);
 int adsb_last_result(adsb_ctx* ctx, const adsb_burst** bursts, int32_t* n);
 
 /* Asynchronous form of adsb_process_*_device: submit queues the whole device pipeline on the context's
@@ -130,6 +150,7 @@ int adsb_last_result(adsb_ctx* ctx, const adsb_burst** bursts, int32_t* n);
 int adsb_submit_iq_device(adsb_ctx* ctx, const void* d_iq, int64_t n, int64_t abs_offset, int32_t* ticket);
 int adsb_submit_mag2_device(adsb_ctx* ctx, const void* d_mag2, int64_t n, int64_t abs_offset, int32_t* ticket);
 int adsb_submit_iq16_device(adsb_ctx* ctx, const void* d_iq16, int64_t n, int64_t abs_offset, int32_t* ticket);
+int adsb_submit_format_device(adsb_ctx* ctx, int format, const void* d_data, int64_t n, int64_t abs_offset, int32_t* ticket);
 int adsb_submit_shard_device(adsb_ctx* ctx, int fmt, const void* d_data, int64_t n, int64_t origin, int64_t own_lo,
                              int64_t own_hi, int64_t stream_len, int32_t head_cands, int32_t* ticket);
 int adsb_wait(adsb_ctx* ctx, int32_t ticket, adsb_burst* out, int32_t cap, int32_t* n_out);
@@ -153,7 +174,7 @@ int adsb_demod_work(adsb_ctx* ctx, const float* in0, int64_t n, int64_t nitems_r
 
 /* Overlapped time shards (multi-GPU): the device buffer holds stream samples [origin, origin+n) of
  * which this shard owns the pulse rises in [own_lo, own_hi) (stream offsets).  stream_len = length of
- * the whole stream (for the end-of-stream rules); fmt 0 = complex64, 1 = float |IQ|^2, 2 = int16 IQ.
+ * the whole stream (for the end-of-stream rules); fmt = ADSB_FMT_*.
  *   head_cands == 0: returns EVERY matched preamble centre of the owned range, not gated (KEPT never
  *     set); adsb_stitch applies the gate over the concatenation of all shards.
  *   head_cands  > 0: the gate runs on the device as if the shard started a fresh stream (KEPT set), and

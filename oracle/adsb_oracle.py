@@ -49,6 +49,20 @@ def mag2_iq16(iq16, scale):
     return re * re + im * im
 
 
+def mag2_iq8(iq8, scale, offset_binary=False):
+    """8-bit interleaved IQ -> |IQ|^2 as the HIP path's ADSB_FMT_SC8 / ADSB_FMT_CU8 formats define it (no reference
+    counterpart).  int8: component = f32(i8) * f32(scale).  Offset binary (RTL-SDR uint8):
+    component = f32(2*u8 - 255) * f32(scale) -- the integer 2*u8-255 is exact, one rounded multiply."""
+    if offset_binary:
+        c = (2 * np.asarray(iq8, dtype=np.uint8).astype(np.int32) - 255).astype(np.float32)
+    else:
+        c = np.asarray(iq8, dtype=np.int8).astype(np.float32)
+    v = c * np.float32(scale)
+    re = np.ascontiguousarray(v[0::2])
+    im = np.ascontiguousarray(v[1::2])
+    return re * re + im * im
+
+
 def snr_db(peak, med):
     """framer.py:157/159: 10.0*np.log10(in0[p]/median) + 1.6 evaluated in float32 (NumPy 2 promotion)."""
     with np.errstate(all="ignore"):

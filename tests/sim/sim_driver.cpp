@@ -19,7 +19,17 @@ struct SimOut {
   long long lastp, last_kept;
 };
 
-// mode 0: data = complex64 (2n floats); mode 1: data = float |IQ|^2.  Returns 0 or -1 (overflow of out).
+#define SIM_BY_MODE(mode, K, ...)                          \
+  switch (mode) {                                          \
+    case 0: hipsim::launch(K<0>, __VA_ARGS__); break;      \
+    case 1: hipsim::launch(K<1>, __VA_ARGS__); break;      \
+    case 2: hipsim::launch(K<2>, __VA_ARGS__); break;      \
+    case 3: hipsim::launch(K<3>, __VA_ARGS__); break;      \
+    default: hipsim::launch(K<4>, __VA_ARGS__); break;     \
+  }
+
+// mode = ADSB_FMT_* (0 complex64, 1 float |IQ|^2, 2 int16 IQ, 3 int8 IQ, 4 uint8 offset-binary IQ).
+// Returns 0 or -1 (overflow of out).
 int sim_run(int mode, const float* data, long long n, long long in0_base, long long scan_lo, long long scan_hi,
             long long fall_hi, long long dem_hi, long long origin, float thr, float prev_in0, int sps,
             int end_is_call_end, long long prev_eob_stream, int gate, int head_n, int grid_max, int rec_cap_in, float scale,
@@ -41,9 +51,9 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   const long long tot = (long long)nlists * rec_cap;
 
   // data must be 16-byte aligned like a device allocation
-  const size_t nfl = (size_t)n * (mode == 0 ? 2 : 1);   // 4-byte units: complex64 = 2, float / int16 IQ = 1
-  float* dbuf = (float*)aligned_alloc(64, ((nfl * 4 + 63) / 64 + 1) * 64);
-  memcpy(dbuf, data, nfl * 4);
+  const size_t nby = (size_t)n * (size_t)mode_bytes(mode);
+  float* dbuf = (float*)aligned_alloc(64, ((nby + 63) / 64 + 1) * 64);
+  memcpy(dbuf, data, nby);
 
   std::vector<unsigned long long> cands(tot), sorted(tot), kept(tot);
   std::vector<Rec> outv(tot);
@@ -63,13 +73,8 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   a.blk_flags = blk_flags.data(); a.longlist = longlist.data(); a.long_count = &long_count;
   a.long_lastp = &long_lastp;
 
-  if (mode == 0) hipsim::launch(k_detect<0>, grid, kThreads, a);
-  else if (mode == 1) hipsim::launch(k_detect<1>, grid, kThreads, a);
-  else hipsim::launch(k_detect<2>, grid, kThreads, a);
-
-  if (mode == 0) hipsim::launch(k_longrun<0>, 3, kThreads, a);
-  else if (mode == 1) hipsim::launch(k_longrun<1>, 3, kThreads, a);
-  else hipsim::launch(k_longrun<2>, 3, kThreads, a);
+  SIM_BY_MODE(mode, k_detect, grid, kThreads, a);
+  SIM_BY_MODE(mode, k_longrun, 3, kThreads, a);
   {
     hipsim::launch(k_scan, 1, kThreads, (const int*)blk_count.data(), (const long long*)blk_lastp.data(),
                    (const unsigned*)blk_flags.data(), nlists, rec_cap, (const int*)&long_count,
@@ -87,12 +92,7 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     hipsim::launch(k_scan2, 1, kThreads, seg.data(), &sum, &long_count, &long_lastp);
     hipsim::launch(k_compact, 3, kThreads, (const unsigned long long*)sorted.data(), &sum, (const int*)seg.data(),
                    fmask, fwant, head_n, kept.data(), (int)tot);
-    if (mode == 0) hipsim::launch(k_burst<0>, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum,
-                                  outv.data(), (int)tot);
-    else if (mode == 1) hipsim::launch(k_burst<1>, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum,
-                                       outv.data(), (int)tot);
-    else hipsim::launch(k_burst<2>, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum,
-                        outv.data(), (int)tot);
+    SIM_BY_MODE(mode, k_burst, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum, outv.data(), (int)tot);
   }
   so->n_rec = sum.n_rec; so->n_kept = sum.n_kept; so->overflow = sum.overflow; so->long_count = sum.long_count;
   so->flags = sum.flags; so->lastp = sum.lastp; so->last_kept = sum.last_kept_p;

@@ -45,9 +45,9 @@ def lib():
 
 def sim_run(mode, data, sps, thr, in0_base, scan_lo, scan_hi, fall_hi, dem_hi, origin=0, prev_in0=0.0,
             end_is_call_end=1, prev_eob_stream=None, gate=True, grid_max=6, rec_cap=0, scale=1.0):
-    """mode 0: complex64[n]; 1: float32 |IQ|^2 [n]; 2: int16 interleaved IQ [2n]."""
-    if mode == 2:
-        data = np.ascontiguousarray(data, dtype=np.int16)
+    """mode 0: complex64[n]; 1: float32 |IQ|^2 [n]; 2: int16 / 3: int8 / 4: uint8 interleaved IQ [2n]."""
+    if mode >= 2:
+        data = np.ascontiguousarray(data, dtype={2: np.int16, 3: np.int8, 4: np.uint8}[mode])
         n = len(data) // 2
     else:
         data = np.ascontiguousarray(data, dtype=np.complex64 if mode == 0 else np.float32)
@@ -71,7 +71,7 @@ def sim_run(mode, data, sps, thr, in0_base, scan_lo, scan_hi, fall_hi, dem_hi, o
 def sim_canonical(mode, data, fs, thr, abs_offset=0, **kw):
     sps = int(fs // 1e6)
     H = 8 * sps
-    n = len(data) // 2 if mode == 2 else len(data)
+    n = len(data) // 2 if mode >= 2 else len(data)
     return sim_run(mode, data, sps, thr, in0_base=-(H - 1), scan_lo=-(H - 1), scan_hi=n - (H - 1), fall_hi=n - (H - 1),
                    dem_hi=n, origin=abs_offset, **kw)
 

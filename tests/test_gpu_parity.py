@@ -54,6 +54,32 @@ def test_canonical_int16_iq_matches_reference_goldens(native, torch_mod, name):
     assert_recs_match_golden(ctx.wait(tk), g)
 
 
+@pytest.mark.parametrize("fs,bps", [(2e6, 2000), (8e6, 6000), (20e6, 2000)])
+@pytest.mark.parametrize("fmt", ["sc8", "cu8"])
+def test_int8_iq_formats_vs_c_oracle(native, torch_mod, fs, bps, fmt):
+    """8-bit IQ ingestion (ADSB_FMT_SC8 / ADSB_FMT_CU8) -- host, device and submitted entry points
+    against the oracle fed with the oracle's own exact conversion of the same bytes."""
+    from gr_adsb_amd import modulator as M
+    from oracle import adsb_oracle as O
+    from oracle import c_oracle as C
+    ob = fmt == "cu8"
+    f = native.FMT_CU8 if ob else native.FMT_SC8
+    n = (1 << 22) + 1234
+    q = M.quantize_iq8(M.synth_iq(n, fs, bps, 21, noise_power=3e-3, amp2_range=(0.2, 1.0)), full_scale=4.0, offset_binary=ob)
+    scale = float(np.float32(4.0 / 255.0 if ob else 4.0 / 127.0))
+    ctx = native.Context(fs, 0.03)
+    ctx.set_format_scale(f, scale)
+    want = C.canonical(O.mag2_iq8(q, scale, ob), int(fs // 1e6), np.float32(0.03))
+    assert len(want) > 500
+    assert_recs_equal(ctx.process_format(f, q), want, fmt + " host")
+    t = torch_mod.from_numpy(q.copy()).to("cuda:0")
+    assert_recs_equal(ctx.process_format_device(f, t.data_ptr(), n), want, fmt + " device")
+    tk = ctx.submit_format_device(f, t.data_ptr(), n)
+    assert_recs_equal(ctx.wait(tk), want, fmt + " submitted")
+    with pytest.raises(native.AdsbError):
+        ctx.set_format_scale(native.FMT_FC32, 1.0)
+
+
 def test_int16_iq_large_vs_c_oracle(native, torch_mod):
     from gr_adsb_amd import modulator as M
     from oracle import adsb_oracle as O

@@ -183,10 +183,8 @@ def main():
         kept = sharding.finish_shard(recs, sps, rank, ag_int, ungated, ag_obj, inplace=inplace)
         return len(kept)
 
-    def ag_int(pair):
-        out = [torch.zeros(2, dtype=torch.int64) for _ in range(n_gpus)]
-        dist.all_gather(out, torch.tensor([int(pair[0]), int(pair[1])], dtype=torch.int64))   # 16 bytes per rank, host side (gloo)
-        return [(int(t[0]), int(t[1])) for t in out]
+    # 16 bytes per rank per pass, host side: shared-memory mailbox on one node, gloo all_gather across nodes
+    ag_int, ag_close = sharding.make_pair_exchange(dist, rank, n_gpus) if n_gpus > 1 else (None, lambda: None)
 
     def ag_obj(o):
         out = [None] * n_gpus
@@ -300,6 +298,7 @@ def main():
         print(json.dumps(result), flush=True)
     if n_gpus > 1:
         dist.barrier()
+        ag_close()
         dist.destroy_process_group()
     return result
 

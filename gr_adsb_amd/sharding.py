@@ -7,11 +7,101 @@ the shard is re-gated on the host (adsb_shard_fixup) and the result is bit-ident
 over the whole stream.  If a shard's head region ends inside an unbroken chain of overlapping bursts (dense
 traffic, tiny head) the ranks fall back to exchanging their full candidate lists (adsb_stitch).
 """
+import mmap
+import os
+import time
+
 import numpy as np
 
 from . import _native
 
 HEAD_CANDS = 64
+
+
+class ShmPairExchange:
+    """all_gather of one (int64, int64) pair per rank per pass through a shared-memory mailbox, for ranks
+    of ONE node (bench.py --gpus N, one process per GPU): a gloo all_gather of 16 bytes costs 0.5-3 ms on
+    loopback TCP -- several times the 0.47 ms GPU pass it accompanies; this costs microseconds.  Ranks on
+    different nodes use the torch.distributed (gloo) all_gather instead -- finish_shard takes either.
+
+    Layout (int64 words): ring of DEPTH entries x world slots x [seq, a, b, check].  Pass k: a rank stores
+    a, b, check = a ^ b ^ MAGIC*(k+1), then seq = k+1 into entry k % DEPTH, and spins until every slot of the
+    entry shows seq == k+1 WITH a matching check word (so a reader can never pair a new seq with stale values,
+    whatever the store ordering of the host CPU).  A rank writes pass k+1 only after it has read pass k
+    completely, i.e. after every rank wrote pass k, i.e. after every rank finished reading pass k-1: entry
+    (k+1) % DEPTH is free for DEPTH >= 3."""
+    DEPTH = 4
+    WORDS = 4
+    MAGIC = 0x9E3779B97F4A7C15
+
+    def __init__(self, path, rank, world, create):
+        self.rank, self.world, self.path = rank, world, path
+        size = self.DEPTH * world * self.WORDS * 8
+        if create:
+            fd = os.open(path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
+            os.ftruncate(fd, size)
+        else:
+            fd = os.open(path, os.O_RDWR)
+        self._mm = mmap.mmap(fd, size)
+        os.close(fd)
+        self._a = np.frombuffer(self._mm, dtype=np.uint64).reshape(self.DEPTH, world, self.WORDS)
+        self._k = 0
+
+    def all_gather_pair(self, pair, timeout=120.0):
+        k = self._k
+        m64 = (1 << 64) - 1
+        e = self._a[k % self.DEPTH]
+        a, b = int(pair[0]) & m64, int(pair[1]) & m64
+        salt = (self.MAGIC * (k + 1)) & m64
+        e[self.rank, 1] = a
+        e[self.rank, 2] = b
+        e[self.rank, 3] = a ^ b ^ salt
+        e[self.rank, 0] = k + 1                      # publish last
+        t0 = None
+        while True:
+            snap = e.copy()
+            if np.all(snap[:, 0] == k + 1) and np.all((snap[:, 1] ^ snap[:, 2] ^ np.uint64(salt)) == snap[:, 3]):
+                break
+            if t0 is None:
+                t0 = time.perf_counter()
+            elif time.perf_counter() - t0 > timeout:
+                raise TimeoutError("shard tail exchange: a rank did not publish pass %d" % k)
+        self._k = k + 1
+        s64 = snap[:, 1:3].astype(np.uint64).view(np.int64)
+        return [(int(s64[r, 0]), int(s64[r, 1])) for r in range(self.world)]
+
+    def close(self):
+        self._a = None
+        try:
+            self._mm.close()
+        except BufferError:
+            pass
+
+
+def make_pair_exchange(dist, rank, world):
+    """The cheapest correct transport for finish_shard's one exchange: a shared-memory mailbox when every
+    rank runs on this node (torchrun sets LOCAL_WORLD_SIZE == WORLD_SIZE; ADSB_SHARD_EXCHANGE=gloo overrides),
+    else the process group's own all_gather.  Returns (all_gather_pair, close)."""
+    import torch
+    same_node = os.environ.get("LOCAL_WORLD_SIZE") == str(world) and os.path.isdir("/dev/shm") \
+        and os.environ.get("ADSB_SHARD_EXCHANGE", "shm") == "shm"
+    if same_node:
+        name = [None]
+        if rank == 0:
+            name[0] = "/dev/shm/adsb_xchg_%d_%d" % (os.getpid(), int(time.time() * 1e6) & 0xFFFFFFFF)
+            ShmPairExchange(name[0], 0, world, create=True).close()
+        dist.broadcast_object_list(name, src=0)
+        x = ShmPairExchange(name[0], rank, world, create=False)
+        dist.barrier()                               # everyone has it mapped ...
+        if rank == 0:
+            os.unlink(name[0])                       # ... so the name can go: nothing is left behind on a crash
+        return x.all_gather_pair, x.close
+
+    def ag(pair):
+        out = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(out, torch.tensor([int(pair[0]), int(pair[1])], dtype=torch.int64))
+        return [(int(t[0]), int(t[1])) for t in out]
+    return ag, (lambda: None)
 
 
 def incoming_eob(tails, rank):

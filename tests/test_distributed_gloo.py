@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, head, bps, q):
+def _worker(rank, world, port, head, bps, q, exchange="gloo"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -39,10 +39,14 @@ def _worker(rank, world, port, head, bps, q):
     def shard(head_cands):
         return simlib.sim_shard(0, iq[p["lo"]:p["hi"]], p["lo"], p["own_lo"], p["own_hi"], n, fs, 0.01, head_cands=head_cands)[0]
 
-    def ag_int(pair):
-        out = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(out, torch.tensor([int(pair[0]), int(pair[1])], dtype=torch.int64))
-        return [(int(t[0]), int(t[1])) for t in out]
+    # the transport bench.py --gpus N picks: shared-memory mailbox on one node, else the gloo all_gather
+    os.environ["ADSB_SHARD_EXCHANGE"] = exchange
+    os.environ["LOCAL_WORLD_SIZE"] = str(world)
+    ag_int, ag_close = sharding.make_pair_exchange(dist, rank, world)
+    assert (ag_int.__self__.__class__.__name__ == "ShmPairExchange") == (exchange == "shm") if hasattr(ag_int, "__self__") else exchange == "gloo"
+    for k in range(300):                          # many passes through the ring, values must never mix
+        got = ag_int((rank * 1000003 + k, -(k + 1) * (rank + 1)))
+        assert got == [(r * 1000003 + k, -(k + 1) * (r + 1)) for r in range(world)]
 
     def ag_obj(o):
         out = [None] * world
@@ -54,11 +58,12 @@ def _worker(rank, world, port, head, bps, q):
     if rank == 0:
         q.put(np.concatenate(allk).tobytes())
     dist.barrier()
+    ag_close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("head,bps", [(64, 6000), (1, 40000)])   # second case forces the full-candidate fallback
-def test_two_rank_shard_stitch_equals_single_call(head, bps):
+@pytest.mark.parametrize("head,bps,exchange", [(64, 6000, "gloo"), (1, 40000, "gloo"), (64, 6000, "shm"), (1, 40000, "shm")])
+def test_two_rank_shard_stitch_equals_single_call(head, bps, exchange):    # head=1 forces the full-candidate fallback
     import torch.multiprocessing as mp
     from gr_adsb_amd import modulator as M
     from oracle import adsb_oracle as O
@@ -68,7 +73,7 @@ def test_two_rank_shard_stitch_equals_single_call(head, bps):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, head, bps, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, head, bps, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     got = np.frombuffer(q.get(timeout=300), dtype=C.REC)

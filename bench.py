@@ -166,6 +166,7 @@ def main():
             return collect_shard(pending.pop(0))
         return 0
 
+    host_t = {"stitch": 0.0}
     stash = {}            # results of tickets that had to be collected early (fallback path only)
 
     def ungated():
@@ -180,7 +181,9 @@ def main():
             recs, inplace = stash.pop(ticket), False
         else:
             recs, inplace = fe.wait(ticket, copy=False), True    # view of the pinned result buffer, fixed up in place
+        t_x = time.perf_counter()
         kept = sharding.finish_shard(recs, sps, rank, ag_int, ungated, ag_obj, inplace=inplace)
+        host_t["stitch"] += time.perf_counter() - t_x
         return len(kept)
 
     # 16 bytes per rank per pass, host side: shared-memory mailbox on one node, gloo all_gather across nodes
@@ -258,6 +261,8 @@ def main():
                 "sharding": "none" if n_gpus == 1 else "%d overlapped time shards, host stitch" % n_gpus,
                 "pipeline": "%d passes in flight (submit/wait)" % DEPTH,
                 "detect_gap_ms_avg": round(st["detect_gap_ms"] / max(1, st["detect_gaps"]), 4),
+                "stitch_ms_per_step_rank0": None if n_gpus == 1 else round(host_t["stitch"] / max(1, args.steps + args.warmup) * 1e3, 4),
+                "stitch_fallbacks_rank0": None if n_gpus == 1 else sharding.STATS["fallbacks"],
                 "detect_grid": int(st["detect_grid"]), "retries": int(st["retries"]), "longrun_calls": int(st["longrun_calls"]),
             },
             "roofline": {

@@ -104,6 +104,9 @@ def make_pair_exchange(dist, rank, world):
     return ag, (lambda: None)
 
 
+STATS = {"fallbacks": 0}     # finish_shard calls that needed the full-candidate exchange (this process)
+
+
 def incoming_eob(tails, rank):
     """eob a shard inherits: the tail of the nearest earlier shard that kept any burst."""
     for t in reversed(tails[:rank]):
@@ -128,6 +131,7 @@ def finish_shard(recs, sps, rank, all_gather_pair, ungated_fn, all_gather_obj, i
         kept = _native.shard_fixup(recs, sps, incoming_eob(tails, rank), inplace=inplace)
         assert kept is not None
         return kept
+    STATS["fallbacks"] += 1
     mine = ungated_fn()
     whole = _native.stitch(np.concatenate(all_gather_obj(mine)), sps)
     return whole[np.isin(whole["offset"], mine["offset"])]

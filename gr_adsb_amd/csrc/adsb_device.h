@@ -168,15 +168,29 @@ __device__ __forceinline__ float mag2_iq8(unsigned iq, float scale) {
 constexpr bool mode_is_iq8(int mode) { return mode == 3 || mode == 4; }
 constexpr int mode_bytes(int mode) { return mode == 0 ? 8 : mode_is_iq8(mode) ? 2 : 4; }   // bytes per sample
 
+// One sample as it lies in memory (RawSel<MODE>::type) and its conversion to |IQ|^2, kept apart so that a
+// gather can be issued long before its value is needed (k_burst fetches the next burst while it works on this one).
+template <int MODE> struct RawSel { using type = float; };
+template <> struct RawSel<0> { using type = float2; };
+template <> struct RawSel<2> { using type = unsigned; };
+template <> struct RawSel<3> { using type = unsigned short; };
+template <> struct RawSel<4> { using type = unsigned short; };
+
+template <int MODE>
+__device__ __forceinline__ typename RawSel<MODE>::type load_raw(const void* data, long long i) {
+  return reinterpret_cast<const typename RawSel<MODE>::type*>(data)[i];
+}
+template <int MODE>
+__device__ __forceinline__ float raw_mag2(typename RawSel<MODE>::type r, float scale) {
+  if constexpr (MODE == 0) return mag2f(r.x, r.y);
+  else if constexpr (MODE == 2) return mag2_iq16(r, scale);
+  else if constexpr (mode_is_iq8(MODE)) return mag2_iq8<MODE>(r, scale);
+  else return r;
+}
+
 template <int MODE>
 __device__ __forceinline__ float load_sample(const void* data, long long i, float scale) {
-  if (MODE == 0) {
-    const float2 q = reinterpret_cast<const float2*>(data)[i];
-    return mag2f(q.x, q.y);
-  }
-  if (MODE == 2) return mag2_iq16(reinterpret_cast<const unsigned*>(data)[i], scale);
-  if (mode_is_iq8(MODE)) return mag2_iq8<MODE>(reinterpret_cast<const unsigned short*>(data)[i], scale);
-  return reinterpret_cast<const float*>(data)[i];
+  return raw_mag2<MODE>(load_raw<MODE>(data, i), scale);
 }
 
 template <int MODE>
@@ -228,31 +242,84 @@ __device__ __forceinline__ float key_f32(unsigned k) {
   return __builtin_bit_cast(float, k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
-// Mode S parity pre-filter for one sliced burst held by a wavefront: lane holds message bits `lane` (bitA) and
-// `64+lane` (bitB, lanes 0..47); ma = ballot(bitA).  Returns kParityOk | kLongFmt | kKnownDf | DF << kDfShift
-// (wave-uniform): the syndromes of the 112- and of the 56-bit reading are XOR-reduced side by side.
-__device__ __forceinline__ unsigned parity_prefilter(bool bitA, bool bitB, unsigned long long ma, int lane) {
-  static constexpr CrcTab tab = make_crc_tab();
-  unsigned sl = (bitA ? tab.r[111 - lane] : 0u) ^ ((bitB && lane < 48) ? tab.r[(47 - lane) & 63] : 0u);
-  unsigned ss = (bitA && lane < 56) ? tab.r[(55 - lane) & 63] : 0u;
-  for (int d2 = 32; d2 >= 1; d2 >>= 1) {
-    sl ^= __shfl_xor(sl, d2);
-    ss ^= __shfl_xor(ss, d2);
+// Mode S parity pre-filter for one sliced burst held by a wavefront.  ma / mb = ballots of message bits 0..63 /
+// 64..111 (wave-uniform).  The syndrome is linear in the message bits, so syndrome bit b is the parity of the
+// message ANDed with a fixed 112-bit mask: lane b (b < 24) owns bit b of the 112-bit reading, lane 32+b bit b of
+// the 56-bit reading, each with its mask in registers (ParityConsts, fetched once per thread; no cross-lane
+// traffic, no per-burst memory access); one ballot collects both syndromes.  Returns kParityOk | kLongFmt | kKnownDf |
+// DF << kDfShift (wave-uniform).
+struct ParityConsts { unsigned long long m1, m2; };
+struct ParityTab { unsigned long long m1[64], m2[64]; };
+constexpr ParityTab make_parity_tab() {
+  ParityTab t{};
+  unsigned v = 1;
+  for (int j = 0; j < 112; ++j) {                    // v = x^j mod G: the contribution of message bit L-1-j
+    for (int b = 0; b < 24; ++b) {
+      const unsigned long long bit = (v >> b) & 1u;
+      const int i = 111 - j;                         // 112-bit reading: lane b
+      if (i < 64) t.m1[b] |= bit << i; else t.m2[b] |= bit << (i - 64);
+      if (j < 56) t.m1[32 + b] |= bit << (55 - j);   // 56-bit reading: lane 32+b
+    }
+    v <<= 1;
+    if (v & 0x1000000u) v ^= 0x1FFF409u;
   }
+  return t;
+}
+// one 16-byte read per thread per kernel launch (loop invariant for every burst the thread's wavefront handles)
+__device__ __forceinline__ ParityConsts parity_consts(int lane) {
+  static constexpr ParityTab tab = make_parity_tab();
+  return ParityConsts{tab.m1[lane], tab.m2[lane]};
+}
+__device__ __forceinline__ unsigned parity_prefilter(unsigned long long ma, unsigned long long mb, const ParityConsts& pc) {
+  const int par = (__popcll(ma & pc.m1) + __popcll(mb & pc.m2)) & 1;
+  const unsigned long long syn = __ballot(par != 0);      // bits 0..23: 112-bit reading, bits 32..55: 56-bit reading
   const unsigned df = (unsigned)(__brevll(ma & 31ull) >> 59);                              // decoder.py:551
   const unsigned dfb = 1u << df;
   const bool lng = (dfb & kDfLongSet) != 0, known = lng || (dfb & kDfShortSet) != 0;
   unsigned flags = df << kDfShift;
   if (lng) flags |= kLongFmt;
   if (known) flags |= kKnownDf;
-  if ((dfb & kDfPiSet) && (lng ? sl : ss) == 0) flags |= kParityOk;                         // decoder.py:625,679
+  if ((dfb & kDfPiSet) && (unsigned)(lng ? syn : (syn >> 32)) == 0) flags |= kParityOk;      // decoder.py:625,679
   return flags;
 }
 
+// The seven gathers of one burst, issued branch-free from clamped (always valid) indices; burst_finish
+// re-derives which of them were in range.  Needs n >= 1.
 template <int MODE>
-__device__ void emit_record(const DetectArgs& a, long long p, unsigned xflags, Rec* out, int lane) {
+struct BurstFetch {
+  using R = typename RawSel<MODE>::type;
+  long long p;
+  unsigned xflags;
+  R peak, w0, w1, x1, x0, y1, y0;
+};
+__device__ __forceinline__ long long clamp_idx(long long i, long long n) { return ((i >= 0) & (i < n)) ? i : 0; }
+
+template <int MODE>
+__device__ __forceinline__ BurstFetch<MODE> burst_issue(const DetectArgs& a, unsigned long long cand, int lane) {
+  BurstFetch<MODE> f;
   const void* d = a.data;
-  const long long n = a.n;
+  const long long n = a.n, p = cand_p(cand);
+  const int sps = a.sps, half = sps >> 1;
+  long long wlo = p - kNoise;
+  if (wlo < a.in0_base) wlo = a.in0_base;
+  const long long s0 = p + 8ll * sps + (long long)lane * sps;             // demod.py:75,87
+  const long long s1 = s0 + 64ll * sps;
+  f.p = p;
+  f.xflags = cand_flags(cand) & (kKept | kHead);
+  f.peak = load_raw<MODE>(d, clamp_idx(p, n));
+  f.w0 = load_raw<MODE>(d, clamp_idx(wlo + lane, n));
+  f.w1 = load_raw<MODE>(d, clamp_idx(wlo + lane + 64, n));
+  f.x1 = load_raw<MODE>(d, clamp_idx(s0, n));
+  f.x0 = load_raw<MODE>(d, clamp_idx(s0 + half, n));                       // demod.py:91
+  f.y1 = load_raw<MODE>(d, clamp_idx(s1, n));
+  f.y0 = load_raw<MODE>(d, clamp_idx(s1 + half, n));
+  return f;
+}
+
+template <int MODE>
+__device__ void burst_finish(const DetectArgs& a, const BurstFetch<MODE>& f, Rec* out, int lane, const ParityConsts& pc) {
+  const long long n = a.n, p = f.p;
+  const unsigned xflags = f.xflags;
   const int sps = a.sps, half = sps >> 1;
   long long wlo = p - kNoise;
   if (wlo < a.in0_base) wlo = a.in0_base;
@@ -260,16 +327,16 @@ __device__ void emit_record(const DetectArgs& a, long long p, unsigned xflags, R
   const bool val0 = lane < nwin, val1 = lane + 64 < nwin;
   const bool dem = p + 119ll * sps + half < a.dem_hi;   // demod.py:76,82 (sps even)
   const bool dem1 = dem && lane < 48;
-  const long long s0 = p + 8ll * sps + (long long)lane * sps;             // demod.py:75,87
+  const long long s0 = p + 8ll * sps + (long long)lane * sps;
   const long long s1 = s0 + 64ll * sps;
-  // every global read of this burst is issued (branch-free) before any of them is used
-  const float peak = xg_nb<MODE>(d, n, p, a.scale);
-  const float w0 = xg_nb<MODE>(d, n, wlo + lane, a.scale);
-  const float w1 = xg_nb<MODE>(d, n, wlo + lane + 64, a.scale);
-  const float x1 = xg_nb<MODE>(d, n, s0, a.scale);
-  const float x0 = xg_nb<MODE>(d, n, s0 + half, a.scale);                          // demod.py:91
-  const float y1 = xg_nb<MODE>(d, n, s1, a.scale);
-  const float y0 = xg_nb<MODE>(d, n, s1 + half, a.scale);
+  auto val = [&](typename RawSel<MODE>::type r, long long i) -> float {     // x(i) = 0 outside the buffer
+    const float v = raw_mag2<MODE>(r, a.scale);
+    return ((i >= 0) & (i < n)) ? v : 0.0f;
+  };
+  const float peak = val(f.peak, p);
+  const float w0 = val(f.w0, wlo + lane), w1 = val(f.w1, wlo + lane + 64);
+  const float x1 = val(f.x1, s0), x0 = val(f.x0, s0 + half);
+  const float y1 = val(f.y1, s1), y0 = val(f.y0, s1 + half);
   const float v0 = val0 ? w0 : 0.0f;
   const float v1 = val1 ? w1 : 0.0f;
 
@@ -303,7 +370,7 @@ __device__ void emit_record(const DetectArgs& a, long long p, unsigned xflags, R
   }
   const bool bitA = dem && x1 > x0, bitB = dem1 && y1 > y0;                                // demod.py:95
   const unsigned long long ma = __ballot(bitA), mb = __ballot(bitB);
-  const unsigned pflags = parity_prefilter(bitA, bitB, ma, lane);
+  const unsigned pflags = parity_prefilter(ma, mb, pc);
   if (lane == 0) {
     const unsigned long long ra = __builtin_bswap64(__brevll(ma));
     const unsigned long long rb = __builtin_bswap64(__brevll(mb)) & 0xFFFFFFFFFFFFull;
@@ -907,9 +974,21 @@ __global__ void __launch_bounds__(kThreads) k_burst(DetectArgs a, const unsigned
   const int nwave = (int)((gridDim.x * (unsigned)kThreads) >> 6);
   int n = sum->n_kept;
   if (n > out_cap) n = out_cap;
+  const ParityConsts pc = parity_consts(lane);
+  if (wave_g >= n) return;
+  // software pipeline over this wavefront's bursts: the gathers of burst t+1 and the list word of burst t+2
+  // are in flight while burst t is reduced (median select, slice, parity) -- otherwise every burst costs two
+  // dependent HBM round trips of an otherwise idle wavefront
+  BurstFetch<MODE> cur = burst_issue<MODE>(a, kept[wave_g], lane);
+  unsigned long long c1 = (wave_g + nwave < n) ? kept[wave_g + nwave] : 0ull;
   for (int t = wave_g; t < n; t += nwave) {
-    const unsigned long long c = kept[t];
-    emit_record<MODE>(a, cand_p(c), cand_flags(c) & (kKept | kHead), out + t, lane);
+    const int tn = t + nwave, t2 = tn + nwave;
+    BurstFetch<MODE> nxt = cur;
+    if (tn < n) nxt = burst_issue<MODE>(a, c1, lane);
+    const unsigned long long c2 = (t2 < n) ? kept[t2] : 0ull;
+    burst_finish<MODE>(a, cur, out + t, lane, pc);
+    cur = nxt;
+    c1 = c2;
   }
 }
 
@@ -924,6 +1003,7 @@ __global__ void __launch_bounds__(kThreads) k_slice(const void* data, long long 
   const int wave_g = (int)((blockIdx.x * (unsigned)kThreads + threadIdx.x) >> 6);
   const int nwave = (int)((gridDim.x * (unsigned)kThreads) >> 6);
   const int half = sps >> 1;
+  const ParityConsts pc = parity_consts(lane);
   for (int t = wave_g; t < ntags; t += nwave) {
     const long long p = tag_idx[t];
     const bool dem = p + 119ll * sps + half < n;
@@ -940,7 +1020,7 @@ __global__ void __launch_bounds__(kThreads) k_slice(const void* data, long long 
       }
     }
     const unsigned long long ma = __ballot(b0), mb = __ballot(b1);
-    const unsigned pflags = parity_prefilter(b0, b1, ma, lane);
+    const unsigned pflags = parity_prefilter(ma, mb, pc);
     if (lane == 0) {
       const unsigned long long ra = __builtin_bswap64(__brevll(ma));
       const unsigned long long rb = __builtin_bswap64(__brevll(mb));

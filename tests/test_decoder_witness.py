@@ -33,7 +33,11 @@ def _decode_all(R, pdus):
     return msgs, {k: repr(sorted(v.items())) if isinstance(v, dict) else repr(v) for k, v in dec.plane_dict.items()}
 
 
-def test_reference_decoder_sees_identical_pdus():
+def test_reference_decoder_sees_identical_pdus(monkeypatch):
+    import time
+    # the reference decoder stamps wall-clock seconds into its aircraft table (decoder.py:424,433,1124): freeze
+    # the clock so the two decoder runs below cannot straddle a second boundary
+    monkeypatch.setattr(time, "time", lambda: 1.7e9)
     import simlib
     from gr_adsb_amd import blocks, _native
     from gr_adsb_amd import modulator as M

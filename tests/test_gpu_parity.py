@@ -353,6 +353,48 @@ def test_full_size_properties(native, torch_mod):
     assert fe.stitch(lists).tobytes() == whole.tobytes()
 
 
+def test_more_than_2_31_samples(native, torch_mod):
+    """Maximum-size edge: one canonical call over 2^31 + 2^20 + 37 samples (int8 IQ, 4.3 GB in HBM), so every
+    64-bit index path is exercised past the int32 range.  Checked by size-independent properties: windows
+    (start, across the 2^31 boundary, ragged end) equal the C oracle on the same bytes; offsets increasing and
+    gated; shards stitched == whole."""
+    torch = torch_mod
+    from gr_adsb_amd import modulator as M
+    from gr_adsb_amd.frontend import FrontEnd, shard_plan
+    from oracle import adsb_oracle as O
+    from oracle import c_oracle as C
+    fs, sps = 2e6, 2
+    nb = 1 << 24
+    block = M.quantize_iq8(M.synth_iq(nb, fs, 2000, 41, noise_power=3e-3, amp2_range=(0.2, 1.0)), full_scale=4.0)
+    n = (1 << 31) + (1 << 20) + 37
+    reps = n // nb + 1
+    dev = torch.from_numpy(block.copy()).to("cuda:0").view(nb, 2)
+    big = dev.repeat(reps, 1)[:n].contiguous()
+    assert big.shape[0] == n and big.dtype == torch.int8
+    scale = float(np.float32(4.0 / 127.0))
+    fe = FrontEnd(fs, 0.03)
+    fe.ctx.set_format_scale(native.FMT_SC8, scale)
+    whole = fe.process_format_tensor(native.FMT_SC8, big)
+    assert len(whole) > 1_000_000 and whole["offset"][-1] > (1 << 31)
+    assert np.diff(whole["offset"]).min() > 63 * sps
+    w = 1 << 21
+    for start in (0, (1 << 31) - w // 2, n - w):
+        host = big[start:start + w].cpu().numpy().reshape(-1)
+        ref = C.canonical(O.mag2_iq8(host, scale), sps, np.float32(0.03), abs_offset=start)
+        lo = start + (2000 if start > 0 else 0)
+        hi = start + w - 2000 if start + w < n else n
+        a = whole[(whole["offset"] >= lo) & (whole["offset"] < hi)]
+        b = ref[(ref["offset"] >= lo) & (ref["offset"] < hi)]
+        common = np.intersect1d(a["offset"][:8], b["offset"][:8])
+        assert len(common), "no common burst near the window start"
+        c0 = common[0]
+        assert_recs_equal(a[a["offset"] >= c0], b[b["offset"] >= c0], "window @%d" % start)
+        assert (a["offset"] >= c0).sum() > 500
+    lists = [fe.shard_tensor(big[p["lo"]:p["hi"]], p["lo"], p["own_lo"], p["own_hi"], n, fmt=native.FMT_SC8)
+             for p in shard_plan(n, 3, sps)]
+    assert fe.stitch(lists).tobytes() == whole.tobytes()
+
+
 def test_adversarial_streams(native):
     """The seam-hunting streams of test_sim_property.py (plateaus and bursts planted on tile / window
     boundaries, exact ties, thresholds on sample values, NaNs) through the real kernels."""

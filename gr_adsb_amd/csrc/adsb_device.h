@@ -283,34 +283,57 @@ __device__ __forceinline__ unsigned parity_prefilter(unsigned long long ma, unsi
   return flags;
 }
 
-// The seven gathers of one burst, issued branch-free from clamped (always valid) indices; burst_finish
-// re-derives which of them were in range.  Needs n >= 1.
+// The seven gathers of one burst.  Fast path (wave-uniform; every burst but the few within ~100 samples of the
+// start or ~136*sps of the end of the buffer): the whole footprint [p-100, p+135.5*sps] lies inside the buffer,
+// so the loads are a scalar base plus 32-bit lane offsets, nothing is clamped and nothing needs re-validating.
+// Slow path: clamped (always valid) indices, burst_finish re-derives which were in range.  Needs n >= 1.
 template <int MODE>
 struct BurstFetch {
   using R = typename RawSel<MODE>::type;
   long long p;
   unsigned xflags;
+  bool fast;
   R peak, w0, w1, x1, x0, y1, y0;
 };
 __device__ __forceinline__ long long clamp_idx(long long i, long long n) { return ((i >= 0) & (i < n)) ? i : 0; }
+__device__ __forceinline__ long long uniform64(long long v) {
+  const unsigned lo = (unsigned)adsb_uniform((int)(unsigned)(unsigned long long)v);
+  const unsigned hi = (unsigned)adsb_uniform((int)(unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
 
 template <int MODE>
 __device__ __forceinline__ BurstFetch<MODE> burst_issue(const DetectArgs& a, unsigned long long cand, int lane) {
+  using R = typename RawSel<MODE>::type;
   BurstFetch<MODE> f;
   const void* d = a.data;
-  const long long n = a.n, p = cand_p(cand);
+  const long long n = a.n, p = uniform64(cand_p(cand));      // the list word is the same in every lane
   const int sps = a.sps, half = sps >> 1;
-  long long wlo = p - kNoise;
-  if (wlo < a.in0_base) wlo = a.in0_base;
-  const long long s0 = p + 8ll * sps + (long long)lane * sps;             // demod.py:75,87
-  const long long s1 = s0 + 64ll * sps;
   f.p = p;
   f.xflags = cand_flags(cand) & (kKept | kHead);
+  const long long w100 = p - kNoise;
+  f.fast = w100 >= 0 && w100 >= a.in0_base && p + 136ll * sps < n;
+  if (f.fast) {
+    const R* b = reinterpret_cast<const R*>(d) + w100;        // scalar base; every offset below is >= 0
+    const unsigned l = (unsigned)lane, us = (unsigned)sps, o0 = (unsigned)kNoise + 8u * us + l * us;
+    f.peak = b[kNoise];
+    f.w0 = b[l];
+    f.w1 = b[l + 64u];
+    f.x1 = b[o0];                                             // demod.py:75,87
+    f.x0 = b[o0 + (unsigned)half];                            // demod.py:91
+    f.y1 = b[o0 + 64u * us];
+    f.y0 = b[o0 + 64u * us + (unsigned)half];
+    return f;
+  }
+  long long wlo = w100;
+  if (wlo < a.in0_base) wlo = a.in0_base;
+  const long long s0 = p + 8ll * sps + (long long)lane * sps;
+  const long long s1 = s0 + 64ll * sps;
   f.peak = load_raw<MODE>(d, clamp_idx(p, n));
   f.w0 = load_raw<MODE>(d, clamp_idx(wlo + lane, n));
   f.w1 = load_raw<MODE>(d, clamp_idx(wlo + lane + 64, n));
   f.x1 = load_raw<MODE>(d, clamp_idx(s0, n));
-  f.x0 = load_raw<MODE>(d, clamp_idx(s0 + half, n));                       // demod.py:91
+  f.x0 = load_raw<MODE>(d, clamp_idx(s0 + half, n));
   f.y1 = load_raw<MODE>(d, clamp_idx(s1, n));
   f.y0 = load_raw<MODE>(d, clamp_idx(s1 + half, n));
   return f;
@@ -321,34 +344,48 @@ __device__ void burst_finish(const DetectArgs& a, const BurstFetch<MODE>& f, Rec
   const long long n = a.n, p = f.p;
   const unsigned xflags = f.xflags;
   const int sps = a.sps, half = sps >> 1;
-  long long wlo = p - kNoise;
-  if (wlo < a.in0_base) wlo = a.in0_base;
-  const int nwin = (int)(p - wlo);
-  const bool val0 = lane < nwin, val1 = lane + 64 < nwin;
   const bool dem = p + 119ll * sps + half < a.dem_hi;   // demod.py:76,82 (sps even)
   const bool dem1 = dem && lane < 48;
-  const long long s0 = p + 8ll * sps + (long long)lane * sps;
-  const long long s1 = s0 + 64ll * sps;
-  auto val = [&](typename RawSel<MODE>::type r, long long i) -> float {     // x(i) = 0 outside the buffer
-    const float v = raw_mag2<MODE>(r, a.scale);
-    return ((i >= 0) & (i < n)) ? v : 0.0f;
-  };
-  const float peak = val(f.peak, p);
-  const float w0 = val(f.w0, wlo + lane), w1 = val(f.w1, wlo + lane + 64);
-  const float x1 = val(f.x1, s0), x0 = val(f.x0, s0 + half);
-  const float y1 = val(f.y1, s1), y0 = val(f.y0, s1 + half);
-  const float v0 = val0 ? w0 : 0.0f;
-  const float v1 = val1 ? w1 : 0.0f;
+  int nwin;
+  float peak, v0, v1, x1, x0, y1, y0;
+  bool val0, val1;
+  if (f.fast) {                                          // wave-uniform
+    nwin = kNoise; val0 = true; val1 = lane < kNoise - 64;
+    peak = raw_mag2<MODE>(f.peak, a.scale);
+    v0 = raw_mag2<MODE>(f.w0, a.scale);
+    v1 = val1 ? raw_mag2<MODE>(f.w1, a.scale) : 0.0f;
+    x1 = raw_mag2<MODE>(f.x1, a.scale); x0 = raw_mag2<MODE>(f.x0, a.scale);
+    y1 = raw_mag2<MODE>(f.y1, a.scale); y0 = raw_mag2<MODE>(f.y0, a.scale);
+  } else {
+    long long wlo = p - kNoise;
+    if (wlo < a.in0_base) wlo = a.in0_base;
+    nwin = (int)(p - wlo);
+    val0 = lane < nwin; val1 = lane + 64 < nwin;
+    const long long s0 = p + 8ll * sps + (long long)lane * sps;
+    const long long s1 = s0 + 64ll * sps;
+    auto val = [&](typename RawSel<MODE>::type r, long long i) -> float {     // x(i) = 0 outside the buffer
+      const float v = raw_mag2<MODE>(r, a.scale);
+      return ((i >= 0) & (i < n)) ? v : 0.0f;
+    };
+    peak = val(f.peak, p);
+    v0 = val0 ? val(f.w0, wlo + lane) : 0.0f;
+    v1 = val1 ? val(f.w1, wlo + lane + 64) : 0.0f;
+    x1 = val(f.x1, s0); x0 = val(f.x0, s0 + half);
+    y1 = val(f.y1, s1); y0 = val(f.y0, s1 + half);
+  }
 
   const unsigned long long nanm = __ballot((val0 && v0 != v0) || (val1 && v1 != v1));
   const unsigned k0 = val0 ? f32_key(v0) : 0xFFFFFFFFu;      // lanes outside the window sort last
   const unsigned k1 = val1 ? f32_key(v1) : 0xFFFFFFFFu;
-  int k = adsb_uniform((nwin - 1) >> 1);                     // lower middle (the middle for odd n)
-  unsigned prefix = 0;                                       // k, prefix, c0 are wave-uniform: scalar registers
+  // exact MSB-first select of the lower middle (the middle for odd n): the answer's known high bits are `prefix`;
+  // bit b is set iff at most kt keys lie below prefix | 1<<b.  One compare per key per step; prefix, c, kt are
+  // wave-uniform and live in scalar registers.
+  const int kt = adsb_uniform((nwin - 1) >> 1);
+  unsigned prefix = 0;
   for (int bit = 31; bit >= 0; --bit) {
-    const unsigned want = prefix >> bit;                     // bucket members whose current bit is 0
-    const int c0 = adsb_uniform(__popcll(__ballot((k0 >> bit) == want)) + __popcll(__ballot((k1 >> bit) == want)));
-    if (k >= c0) { k -= c0; prefix |= 1u << bit; }
+    const unsigned T = prefix | (1u << bit);
+    const int c = adsb_uniform(__popcll(__ballot(k0 < T)) + __popcll(__ballot(k1 < T)));
+    if (c <= kt) prefix = T;
   }
   const unsigned A = prefix;                                 // key of the lower middle
   float med;

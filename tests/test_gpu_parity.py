@@ -395,6 +395,48 @@ def test_more_than_2_31_samples(native, torch_mod):
     assert fe.stitch(lists).tobytes() == whole.tobytes()
 
 
+@pytest.mark.parametrize("fmt", ["fc32", "sc16", "sc8", "cu8"])
+def test_file_replay_equals_one_canonical_call(native, tmp_path, fmt):
+    """SURVEY.md §8f-3 file-source framing: a raw IQ recording replayed block by block (gr_adsb_amd.replay: overlapped
+    shards on one GPU, end-of-burst state carried on the host) == the oracle's single canonical call over the
+    whole file; the CLI records the same PDUs into SQLite."""
+    import os
+    from gr_adsb_amd import modulator as M, pdu_store, replay
+    from oracle import adsb_oracle as O
+    from oracle import c_oracle as C
+    fs, sps, n = 4e6, 4, (1 << 21) + 4321
+    iq = M.synth_iq(n, fs, 4000, 23, noise_power=3e-3, amp2_range=(0.2, 1.0))
+    scale = None
+    if fmt == "fc32":
+        raw, x = iq, O.mag2(iq)
+    elif fmt == "sc16":
+        raw = M.quantize_iq16(iq, full_scale=4.0); scale = float(np.float32(4.0 / 32767.0)); x = O.mag2_iq16(raw, scale)
+    else:
+        ob = fmt == "cu8"
+        raw = M.quantize_iq8(iq, full_scale=4.0, offset_binary=ob)
+        scale = float(np.float32(4.0 / 255.0 if ob else 4.0 / 127.0)); x = O.mag2_iq8(raw, scale, ob)
+    path = os.path.join(tmp_path, "capture." + fmt)
+    raw.tofile(path)
+    want = C.canonical(x, sps, np.float32(0.03))
+    assert len(want) > 500
+    rp = replay.FileReplay(path, fmt, fs, 0.03, block_samples=1 << 18, scale=scale)
+    parts = list(rp)
+    assert len(parts) == 9
+    assert_recs_equal(np.concatenate(parts), want, "replay " + fmt)
+    db = os.path.join(tmp_path, "pdus.db")
+    argv = [path, "--format", fmt, "--fs", str(fs), "--threshold", "0.03", "--block-log2", "19", "--sqlite", db]
+    if scale is not None:
+        argv += ["--scale", repr(scale)]
+    assert replay.main(argv) == 0
+    pdus = pdu_store.read_pdus(db)
+    dem = (want["flags"] & 1) != 0
+    assert len(pdus) == dem.sum()
+    assert np.array_equal(np.array([v for _, v in pdus]), unpack(want["bits"][dem]))
+    # empty recording
+    open(os.path.join(tmp_path, "empty.bin"), "wb").close()
+    assert len(replay.FileReplay(os.path.join(tmp_path, "empty.bin"), fmt, fs, 0.03).all()) == 0
+
+
 def test_adversarial_streams(native):
     """The seam-hunting streams of test_sim_property.py (plateaus and bursts planted on tile / window
     boundaries, exact ties, thresholds on sample values, NaNs) through the real kernels."""

@@ -201,3 +201,26 @@ def test_canonical_int8_iq_formats_match_oracle(name, mode):
     # and the same records come out of the float |IQ|^2 entry fed with the oracle's conversion
     recs1, _ = simlib.sim_canonical(1, x, g.fs, g.thr)
     assert_recs_equal(recs, recs1, "int8 vs mag2 entry")
+
+
+@pytest.mark.parametrize("bps,block,head,growth", [(3000, 1 << 14, 64, 16), (40000, 1 << 13, 1, 1), (6000, 5000, 64, 16)])
+def test_replay_blocks_equal_one_canonical_call(bps, block, head, growth, monkeypatch):
+    """gr_adsb_amd.replay: a recording processed block by block (overlapped shards, host fix-up with the carried
+    end-of-burst state, greedy fallback for dense traffic / tiny heads) == one canonical call over all of it."""
+    from gr_adsb_amd import replay
+    fs, sps, n = 2e6, 2, (1 << 16) + 777
+    iq = M.synth_iq(n, fs, bps, seed=19)
+
+    def shard_fn(plan, head_cands):
+        return simlib.sim_shard(0, iq[plan["lo"]:plan["hi"]], plan["lo"], plan["own_lo"], plan["own_hi"], n, fs, 0.01,
+                                head_cands=head_cands)[0]
+
+    fallbacks = []
+    gate = replay.greedy_gate
+    monkeypatch.setattr(replay, "greedy_gate", lambda *a: (fallbacks.append(1), gate(*a))[1])
+    parts = list(replay.replay_blocks(n, sps, block, shard_fn, head_cands=head, head_growth=growth))
+    assert len(parts) >= 4 and (len(fallbacks) > 0) == (head == 1)
+    got = np.concatenate(parts)
+    want = C.canonical(O.mag2(iq), sps, np.float32(0.01))
+    assert_recs_equal(got, want, "replay")
+    assert np.all((got["flags"] & 2) != 0) and not np.any(got["flags"] & 16)

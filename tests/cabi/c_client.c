@@ -1,0 +1,91 @@
+/* c_client.c -- a plain C99 consumer of include/adsb_hip.h: proves the drop-in boundary needs nothing but the
+ * header and libadsb_hip.so (no Python, no torch, no C++).  Test infrastructure.
+ *
+ *   c_client <fs> <threshold> <iq.f32> <expected.rec>   complex64 IQ file in, 32-byte adsb_burst records expected
+ * exit 0 = identical, 2 = mismatch, 3 = no HIP device (adsb_create -> -ENODEV), 4 = usage / IO, 5 = ABI misuse
+ * checks failed. */
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "adsb_hip.h"
+
+static void* slurp(const char* path, size_t* bytes) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return NULL;
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  void* p = malloc(n > 0 ? (size_t)n : 1);
+  if (p && n > 0 && fread(p, 1, (size_t)n, f) != (size_t)n) { free(p); p = NULL; }
+  fclose(f);
+  *bytes = (size_t)(n > 0 ? n : 0);
+  return p;
+}
+
+int main(int argc, char** argv) {
+  if (sizeof(adsb_burst) != 32 || adsb_abi_version() != ADSB_ABI_VERSION) return 5;
+  if (argc < 5) { fprintf(stderr, "usage: c_client fs threshold iq.f32 expected.rec\n"); return 4; }
+  const double fs = atof(argv[1]);
+  const float thr = (float)atof(argv[2]);
+  adsb_ctx* c = NULL;
+  /* argument checking happens before any device is touched */
+  if (adsb_create(2.5e6, thr, 0, 0, &c) != -EINVAL || c != NULL) return 5;
+  int rc = adsb_create(fs, thr, 0, 0, &c);
+  if (rc == -ENODEV) { fprintf(stderr, "no HIP device: adsb_create -> -ENODEV (there is no CPU fallback)\n"); return 3; }
+  if (rc != 0 || !c) { fprintf(stderr, "adsb_create: %d\n", rc); return 4; }
+
+  size_t nb = 0, eb = 0;
+  float* iq = (float*)slurp(argv[3], &nb);
+  adsb_burst* want = (adsb_burst*)slurp(argv[4], &eb);
+  if (!iq || !want) { fprintf(stderr, "cannot read inputs\n"); return 4; }
+  const int64_t n = (int64_t)(nb / 8);
+  const int32_t nwant = (int32_t)(eb / sizeof(adsb_burst));
+
+  /* too small an output array: -ENOSPC and the required count */
+  int32_t n_out = -1;
+  adsb_burst one;
+  rc = adsb_process_iq(c, iq, n, 0, &one, 1, &n_out);
+  if (nwant > 1 && (rc != -ENOSPC || n_out != nwant)) { fprintf(stderr, "ENOSPC path: rc %d n_out %d\n", rc, n_out); return 5; }
+  if (nwant > 1 && strlen(adsb_last_error(c)) == 0) return 5;
+
+  adsb_burst* got = (adsb_burst*)calloc((size_t)nwant + 1, sizeof(adsb_burst));
+  /* pinned input buffer: the DMA fast path */
+  void* pinned = NULL;
+  if (adsb_host_alloc(&pinned, nb ? nb : 1) != 0) return 4;
+  memcpy(pinned, iq, nb);
+  rc = adsb_process_iq(c, (const float*)pinned, n, 0, got, nwant + 1, &n_out);
+  if (rc != 0) { fprintf(stderr, "adsb_process_iq: %d (%s)\n", rc, adsb_last_error(c)); return 4; }
+  int bad = (n_out != nwant);
+  for (int32_t i = 0; !bad && i < nwant; ++i) {
+    /* compare what the reference defines (offset, SNR inputs, bits, PDU/no PDU); the oracle file carries no
+     * parity pre-filter bits */
+    bad = got[i].offset != want[i].offset || memcmp(&got[i].peak, &want[i].peak, 4) || memcmp(&got[i].median, &want[i].median, 4) ||
+          memcmp(got[i].bits, want[i].bits, 14) || ((got[i].flags ^ want[i].flags) & ADSB_BURST_DEMOD);
+    if (!bad && (got[i].flags & ADSB_BURST_DEMOD)) {
+      int32_t df = -1, nbits = -1;
+      const uint32_t syn = adsb_mode_s_syndrome(got[i].bits, &df, &nbits);
+      const int pi = df == 11 || df == 17 || df == 18 || df == 19;
+      if ((uint32_t)df != ADSB_BURST_DF(got[i].flags) || ((got[i].flags & ADSB_BURST_PARITY_OK) != 0) != (pi && syn == 0)) bad = 1;
+    }
+  }
+  /* the same through the float |IQ|^2 entry (the framer's own input type) computed here in C */
+  float* x = (float*)malloc((size_t)(n > 0 ? n : 1) * sizeof(float));
+  for (int64_t i = 0; i < n; ++i) {
+    volatile float a = iq[2 * i] * iq[2 * i], b = iq[2 * i + 1] * iq[2 * i + 1];
+    x[i] = a + b;
+  }
+  int32_t n2 = -1;
+  rc = adsb_process_mag2(c, x, n, 0, NULL, 0, &n2);
+  const adsb_burst* last = NULL;
+  int32_t nlast = -1;
+  if (rc != 0 || n2 != nwant || adsb_last_result(c, &last, &nlast) != 0 || nlast != nwant ||
+      (nwant > 0 && memcmp(last, got, (size_t)nwant * sizeof(adsb_burst)) != 0)) bad = 1;
+
+  printf("%d bursts, %s\n", (int)n_out, bad ? "MISMATCH" : "identical");
+  adsb_host_free(pinned);
+  adsb_destroy(c);
+  free(got); free(x); free(iq); free(want);
+  return bad ? 2 : 0;
+}

@@ -54,7 +54,7 @@ def pmc_traffic(fs, log2n, bursts):
     return None
 
 
-def cpu_baseline(iq_host, sps, thr, reps=3):
+def cpu_baseline(iq_host, sps, thr, reps=5):
     """Single-core C port of the reference path (oracle/adsb_oracle.c) on a bounded sample."""
     from oracle import c_oracle as C
     C.lib()
@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--bursts", type=float, default=1000.0, help="bursts per second of signal")
     ap.add_argument("--threshold", type=float, default=0.01)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-log2n", type=int, default=26, help="log2 of the CPU-baseline sample")
+    ap.add_argument("--cpu-log2n", type=int, default=28, help="log2 of the CPU-baseline sample (default: one whole step)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--format", choices=["fc32", "sc16", "sc8", "cu8"], default="fc32",
                     help="input sample format: complex64 (BASELINE workload), int16 IQ (4 B/sample) or 8-bit IQ "
@@ -288,11 +288,12 @@ def main():
             match = (len(grecs) == len(crecs) and np.array_equal(grecs["offset"], crecs["offset"])
                      and np.array_equal(grecs["bits"], crecs["bits"])
                      and np.array_equal(grecs["median"].view(np.uint32), crecs["median"].view(np.uint32))
+                     and np.array_equal(grecs["peak"].view(np.uint32), crecs["peak"].view(np.uint32))
                      and np.array_equal(grecs["flags"] & 1, crecs["flags"] & 1))
             result["cpu_baseline"] = {
                 "value": round(msps, 1), "unit": "Msamples/s", "cores": 1, "kind": "port",
                 "sample": "first 2^%d samples of the same stream, oracle/adsb_oracle.c (scalar C restatement of "
-                          "the reference path incl. |IQ|^2), best of 3, host has %d cpus" % (int(np.log2(n_cpu)), os.cpu_count()),
+                          "the reference path incl. |IQ|^2), best of 5 (about 6 s of CPU work), host has %d cpus" % (int(np.log2(n_cpu)), os.cpu_count()),
             }
             result["bit_match"] = {"sample_bursts": int(len(crecs)), "identical": bool(match)}
             nthr = min(64, os.cpu_count() or 1)

@@ -175,8 +175,11 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   if (c->split_tail) {
     // tail on its own stream, ordered after this pass's k_detect/k_longrun only: the next pass's k_detect can
     // start on the compute stream while this runs
-    HIPCHK(c, hipEventRecord(s.det_done, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->tail_stream, s.det_done, 0));
+    // with timing on, the event that closes k_detect's bracket doubles as the dependency (one marker fewer between
+    // consecutive k_detect launches on the compute stream)
+    hipEvent_t dep = s.ev1_valid ? s.ev1 : s.det_done;
+    if (!s.ev1_valid) HIPCHK(c, hipEventRecord(dep, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->tail_stream, dep, 0));
     ts = c->tail_stream;
   }
   // no-op unless k_detect listed pulses longer than its LDS window

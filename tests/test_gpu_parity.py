@@ -437,6 +437,54 @@ def test_file_replay_equals_one_canonical_call(native, tmp_path, fmt):
     assert len(replay.FileReplay(os.path.join(tmp_path, "empty.bin"), fmt, fs, 0.03).all()) == 0
 
 
+def test_caller_stream_and_reset(native, torch_mod):
+    """adsb_set_stream: the pipeline runs on the caller's HIP stream, so input produced by kernels queued on that
+    stream needs no host synchronisation.  adsb_reset: the GNU Radio emulation state (framer.py:54,57) starts over."""
+    torch = torch_mod
+    from gr_adsb_amd import modulator as M
+    from gr_adsb_amd.frontend import FrontEnd
+    from oracle import adsb_oracle as O
+    from oracle import c_oracle as C
+    fs, sps, n = 2e6, 2, 1 << 22
+    iq = M.synth_iq(n, fs, 3000, 77)
+    want = C.process_iq(iq, sps, 0.01)
+    fe = FrontEnd(fs, 0.01)
+    st = torch.cuda.Stream()
+    fe.use_torch_stream(st)
+    base = to_dev(torch, iq)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        for k in range(3):
+            t = (base * 3.0) / 3.0 if k else base + 0.0       # produced on `st` right before the call, no sync
+            got = fe.process_iq_tensor(t)
+            ref = want if k == 0 else C.process_iq(t.cpu().numpy().view(np.complex64).reshape(-1), sps, 0.01)
+            assert_recs_equal(got, ref, "caller stream pass %d" % k)
+    with pytest.raises(native.AdsbError):
+        tk = fe.submit_iq_tensor(base)
+        try:
+            fe.use_torch_stream(st)                           # -EBUSY while a submitted call is pending
+        finally:
+            fe.wait(tk)
+    # reset: two identical framer.work() sequences give identical tags only if the state starts over
+    x = O.mag2(iq[:1 << 16])
+    ctx = native.Context(fs, 0.01)
+    H = 8 * sps
+
+    def run():
+        tags = []
+        pad = np.concatenate([np.zeros(H - 1, np.float32), x])
+        pos = 0
+        for N in (4096,) * 16:
+            tags.append(ctx.framer_work(pad[pos:pos + N + H - 1], N, pos)["offset"].copy())
+            pos += N
+        return np.concatenate(tags)
+    a = run()
+    ctx.reset()
+    b = run()
+    o = O.run_stream(x, fs, 0.01, [4096] * 16)
+    assert np.array_equal(a, o["tag_offsets"]) and np.array_equal(b, a) and len(a) > 50
+
+
 def test_adversarial_streams(native):
     """The seam-hunting streams of test_sim_property.py (plateaus and bursts planted on tile / window
     boundaries, exact ties, thresholds on sample values, NaNs) through the real kernels."""

@@ -159,7 +159,7 @@ def main():
             if len(pending) == DEPTH:
                 return fe.wait(pending.pop(0), fetch=False)
             return 0
-        # N>1: same two-deep pipeline; the host stitch of pass i (two tiny all_gathers) overlaps the GPU pass i+1
+        # N>1: same DEPTH-deep pipeline; the host stitch of pass i (one 16-byte exchange) overlaps the GPU passes after it
         pending.append(fe.submit_shard_tensor(iq, plan["lo"], plan["own_lo"], plan["own_hi"], stream_len,
                                               head_cands=sharding.HEAD_CANDS))
         if len(pending) == DEPTH:

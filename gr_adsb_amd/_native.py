@@ -160,7 +160,7 @@ class Context:
 
     def last_result(self, copy=True):
         """Bursts of the last finished call.  copy=False returns a writable view of the context's pinned
-        buffer, valid until the same pipeline slot is used again (two calls later)."""
+        buffer, valid until the same pipeline slot is used again (MAX_IN_FLIGHT submissions later)."""
         p = ctypes.c_void_p()
         n = ctypes.c_int32(0)
         self._chk(self.lib.adsb_last_result(self._h, ctypes.byref(p), ctypes.byref(n)))

@@ -92,7 +92,7 @@ class FrontEnd:
         return self.ctx.submit_iq16_device(t.data_ptr(), t.shape[0], abs_offset)
 
     def submit_iq_tensor(self, t, abs_offset=0):
-        """Queue a canonical pass over t (two may be in flight); returns a ticket for wait()."""
+        """Queue a canonical pass over t (up to _native.MAX_IN_FLIGHT in flight); returns a ticket for wait()."""
         assert t.is_cuda and t.is_contiguous()
         return self.ctx.submit_iq_device(t.data_ptr(), t.shape[0], abs_offset)
 

@@ -12,7 +12,7 @@
  *   adsb_process_iq[_device]        complex_to_mag_squared -> framer -> demod as wired in
  *                                   examples/adsb_rx.py:180-196 (one canonical work() call per block)
  *   adsb_process_mag2[_device]      the same chain from the framer's float input onwards
- *   adsb_submit_*_device / adsb_wait   the same, two calls in flight (no reference counterpart: pipelining)
+ *   adsb_submit_*_device / adsb_wait   the same, up to ADSB_MAX_IN_FLIGHT calls in flight (no reference counterpart: pipelining)
  *   adsb_shard_device / adsb_shard_fixup / adsb_stitch   (no reference counterpart: overlapped time shards, host stitch)
  *
  * Conventions: the caller owns every buffer it passes; the library owns device memory, pinned staging
@@ -95,7 +95,11 @@ int adsb_abi_version(void);
 int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx** out);
 void adsb_destroy(adsb_ctx* ctx);
 int adsb_set_threshold(adsb_ctx* ctx, float threshold);
-/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. */
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own compute stream: device
+ * input produced by work queued on that stream needs no host synchronisation before adsb_process_*_device /
+ * adsb_submit_*.  With the context's own stream (the default) the caller synchronises producers of a device
+ * buffer first.  -EBUSY while submitted calls are pending.  A context is used from one thread at a time;
+ * different contexts are independent. */
 int adsb_set_stream(adsb_ctx* ctx, void* hip_stream);
 /* Forget the framer's cross-call state (prev_in0 = 0, prev_eob = -1; framer.py:54,57). */
 int adsb_reset(adsb_ctx* ctx);

@@ -34,7 +34,7 @@ EXPORTS = [
     "adsb_submit_iq_device", "adsb_submit_mag2_device", "adsb_submit_iq16_device", "adsb_submit_shard_device", "adsb_wait",
     "adsb_set_iq16_scale", "adsb_process_iq16", "adsb_process_iq16_device",
     "adsb_set_format_scale", "adsb_process_format", "adsb_process_format_device", "adsb_submit_format_device",
-    "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_mode_s_syndrome", "adsb_get_stats",
+    "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_shard_host", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_mode_s_syndrome", "adsb_get_stats",
     "adsb_reset_stats", "adsb_last_error", "adsb_host_alloc", "adsb_host_free",
 ]
 
@@ -100,6 +100,7 @@ def load():
     lib.adsb_framer_work.argtypes = [vp, vp, i64, i64, i64, vp, i32, c.POINTER(i32)]
     lib.adsb_demod_work.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp, vp]
     lib.adsb_shard_device.argtypes = [vp, c.c_int, vp, i64, i64, i64, i64, i64, i32, vp, i32, c.POINTER(i32)]
+    lib.adsb_shard_host.argtypes = [vp, c.c_int, vp, i64, i64, i64, i64, i64, i32, c.c_uint32, vp, i32, c.POINTER(i32)]
     lib.adsb_shard_fixup.argtypes = [vp, i32, c.c_int, i64, c.POINTER(i32)]
     lib.adsb_stitch.argtypes = [vp, i32, c.c_int, c.POINTER(i32)]
     lib.adsb_snr_db.argtypes = [f32, f32]
@@ -281,6 +282,16 @@ class Context:
                                              int(own_hi), int(stream_len), int(head_cands), None, 0, ctypes.byref(n_out)))
         return self.last_result()
 
+    def shard_host(self, fmt, data, origin, own_lo, own_hi, stream_len, head_cands=0, drop_overlong=False):
+        """adsb_shard_host: data = host array in the format's layout (see FMT_LAYOUT)."""
+        dt, per = FMT_LAYOUT[int(fmt)]
+        data = np.ascontiguousarray(data, dtype=dt)
+        n_out = ctypes.c_int32(0)
+        self._chk(self.lib.adsb_shard_host(self._h, int(fmt), ctypes.c_void_p(data.ctypes.data), len(data) // per, int(origin),
+                                           int(own_lo), int(own_hi), int(stream_len), int(head_cands),
+                                           SHARD_DROP_OVERLONG if drop_overlong else 0, None, 0, ctypes.byref(n_out)))
+        return self.last_result()
+
     def stats(self):
         s = Stats()
         self._chk(self.lib.adsb_get_stats(self._h, ctypes.byref(s)))
@@ -325,6 +336,8 @@ def stitch(cands, sps):
 
 
 BURST_HEAD = 16
+SHARD_DROP_OVERLONG = 1
+STREAM_UNBOUNDED = 1 << 60     # stream_len of a stream whose end is not known yet
 MAX_HEAD = 4096          # upper bound on head_cands callers use
 EOB_NONE = -(1 << 60)
 

@@ -40,8 +40,16 @@ def make_pdu(start_timestamp, fs, offset, snr, bits112):
 class framer(gr.sync_block):
     """ADS-B preamble detector / tagger (reference python/adsb/framer.py:33-182)."""
 
-    def __init__(self, fs, threshold, device=0):
+    def __init__(self, fs, threshold, device=0, improved=False):
+        """improved (extension; default off = the reference's behaviour bit for bit): the tags no
+        longer depend on how the scheduler chunks the stream -- pulses straddling a work() boundary are evaluated
+        (framer.py:98-108 drops them), the re-trigger state never goes stale (framer.py:177-179) -- and equal those of
+        ONE reference work() call over the whole stream.  Price: the block delays its output by `self.delay` samples
+        (256 + 121*sps: the look-ahead a complete pulse + burst needs), so that every tag lands on a sample it has
+        not produced yet; tag values become ("SOB", snr, input_offset).  Pulses longer than 256 samples are not
+        evaluated."""
         gr.sync_block.__init__(self, name="ADS-B Framer", in_sig=[np.float32], out_sig=[np.float32])
+        self.improved = bool(improved)
         self.fs = fs
         assert self.fs % SYMBOL_RATE == 0, \
             "ADS-B Framer is designed to operate on an integer number of samples per symbol, not %f sps" % (self.fs / SYMBOL_RATE)
@@ -51,6 +59,12 @@ class framer(gr.sync_block):
             raise ValueError("fs must be an even multiple of 1 MHz (the reference's tap stride is sps//2)")
         self.threshold = threshold
         self.N_hist = NUM_PREAMBLE_BITS * self.sps
+        self.delay = 0
+        if self.improved:
+            self._back = 100 + 8 * self.sps + 4          # noise window + preamble span behind the first owned rise
+            self.delay = 256 + 121 * self.sps             # longest pulse followed + preamble + 112 bits ahead of the last
+            self.N_hist = self._back + self.delay + 1
+            self._eob = _native.EOB_NONE                  # end-of-burst state carried between calls (stream offsets)
         self.set_history(self.N_hist)
         self.set_tag_propagation_policy(gr.TPP_ONE_TO_ONE)
         self._ctx = _native.Context(fs, threshold, device=device)
@@ -62,11 +76,44 @@ class framer(gr.sync_block):
     def prev_eob_idx(self):
         return None
 
+    def _work_improved(self, in0, out0):
+        """One overlapped shard of the unbounded input stream per call (the multi-GPU stitching machinery used in
+        time): in0 = [back halo | N owned samples | look-ahead]; owned = pulse rises in input offsets
+        [nread - delay, nread - delay + N); the gate state crosses calls as one number (adsb_shard_fixup)."""
+        N = len(out0)
+        nread = self.nitems_read(0)
+        B, F = self._back, self.delay
+        buf = in0[:N + B + F]
+        origin = nread - (B + F)                          # input offset of in0[0] (negative: GR's zero history)
+        own_lo, own_hi = nread - F, nread - F + N
+        kept = None
+        for hc in (64, _native.MAX_HEAD):
+            recs = self._ctx.shard_host(_native.FMT_MAG2, buf, origin, own_lo, own_hi, _native.STREAM_UNBOUNDED,
+                                        head_cands=hc, drop_overlong=True)
+            kept = _native.shard_fixup(recs, self.sps, self._eob)
+            if kept is not None:
+                break
+        if kept is None:                                  # an unbroken chain of overlapping bursts longer than the head
+            from .replay import greedy_gate
+            kept = greedy_gate(self._ctx.shard_host(_native.FMT_MAG2, buf, origin, own_lo, own_hi, _native.STREAM_UNBOUNDED,
+                                                    head_cands=0, drop_overlong=True), self.sps, self._eob)
+        if len(kept):
+            self._eob = int(kept["offset"][-1]) + 63 * self.sps
+        snr = _native.snr_db(kept["peak"], kept["median"])
+        for b, s_ in zip(kept, snr):
+            off = int(b["offset"])
+            self.add_item_tag(0, off + F, pmt.to_pmt("burst"),
+                              pmt.to_pmt(("SOB", float(s_) if HAVE_GNURADIO else s_, off)), pmt.to_pmt("framer"))
+        out0[:] = in0[B:B + N]                            # the input delayed by F samples
+        return N
+
     def work(self, input_items, output_items):
         in0 = input_items[0]
         out0 = output_items[0]
         N = len(out0)
         self._ctx.set_threshold(self.threshold)
+        if self.improved:
+            return self._work_improved(in0, out0)
         bursts = self._ctx.framer_work(in0[:N + self.N_hist - 1], N, self.nitems_written(0))
         snr = _native.snr_db(bursts["peak"], bursts["median"])
         for b, s in zip(bursts, snr):
@@ -96,14 +143,23 @@ def _prefilter_pass(flags, df):
 class demod(gr.sync_block):
     """PPM bit slicer / PDU publisher (reference python/adsb/demod.py:31-136)."""
 
-    def __init__(self, fs, device=0, parity_filter=False):
-        """parity_filter (extension, default off = the reference's behaviour: every PDU is published): when
+    def __init__(self, fs, device=0, parity_filter=False, improved=False):
+        """improved (extension; default off): a burst that straddles the end of a work() chunk is
+        completed with the next chunk's samples instead of being dropped for good (demod.py:61-64,130-133 is a stub
+        that never completes it); with a 3-element tag value from the improved framer the PDU timestamp uses the
+        undelayed input offset.
+
+        parity_filter (extension, default off = the reference's behaviour: every PDU is published): when
         True, PDUs the decoder's check_parity() would reject outright -- unknown DF, or DF 11/17/18/19 with
         a non-zero syndrome (decoder.py:560-688) -- are counted in `self.filtered` and not published.  Only
         for decoders run with error_corr="None": a dropped PDU can no longer be repaired by their FEC."""
         gr.sync_block.__init__(self, name="demod", in_sig=[np.float32], out_sig=[np.float32])
         self.parity_filter = bool(parity_filter)
         self.filtered = 0
+        self.improved = bool(improved)
+        self._carry = np.zeros(0, dtype=np.float32)      # improved: tail of the previous chunk(s) ...
+        self._carry_pos = 0                               # ... and the stream offset of its first sample
+        self._pending = []                                # improved: tags whose burst was not complete yet
         self.fs = fs
         assert self.fs % SYMBOL_RATE == 0, \
             "ADS-B Demodulator is designed to operate on an integer number of samples per symbol, not %f sps" % (self.fs / SYMBOL_RATE)
@@ -126,7 +182,9 @@ class demod(gr.sync_block):
             self.straddled_packet = 0
         nread = self.nitems_read(0)
         tags = self.get_tags_in_range(0, nread, nread + len(in0), pmt.to_pmt("burst"))
-        if len(tags):
+        if self.improved:
+            self._work_improved(in0, nread, tags)
+        elif len(tags):
             offs = np.array([t.offset for t in tags], dtype=np.int64)
             # demod.py:79 indexes with nitems_written(0); equal to nitems_read(0) for this sync block
             bits, ok, ratio = self._ctx.demod_work(in0, self.nitems_written(0), offs, want_ratio=self.want_confidence)
@@ -148,3 +206,41 @@ class demod(gr.sync_block):
                                       make_pdu(self.start_timestamp, self.fs, tag.offset, snr, self.bits))
         out0[:] = in0
         return len(out0)
+
+    def _work_improved(self, in0, nread, tags):
+        pend = self._pending + [(int(t.offset), pmt.to_python(t.value)) for t in tags]
+        self._pending = []
+        span = 120 * self.sps                             # samples a burst needs from its tag offset on (demod.py:76)
+        if pend:
+            first = min(o for o, _ in pend)
+            if len(self._carry) and first < nread:
+                buf = np.concatenate([self._carry, in0])
+                pos = self._carry_pos
+            else:
+                buf, pos = in0, nread
+            offs = np.array([o for o, _ in pend], dtype=np.int64)
+            bits, ok, ratio = self._ctx.demod_work(buf, pos, offs, want_ratio=self.want_confidence)
+            pf = self._ctx.last_demod_flags
+            for i, (off, value) in enumerate(pend):
+                if not ok[i]:
+                    self._pending.append((off, value))    # completed by a later call
+                    continue
+                if self.parity_filter and not _prefilter_pass(int(pf[i]), int(bits[i][:5] @ _DF_WEIGHTS)):
+                    self.filtered += 1
+                    continue
+                self.bits = bits[i].copy()
+                if ratio is not None:
+                    with np.errstate(all="ignore"):
+                        self.bit_confidence = np.float32(10.0) * np.log10(ratio[i])
+                t_off = value[2] if len(value) > 2 else off
+                self.message_port_pub(pmt.to_pmt("demodulated"),
+                                      make_pdu(self.start_timestamp, self.fs, t_off, value[1], self.bits))
+        # keep the samples the still incomplete bursts start in (every tag of a chunk is visible in that chunk's call)
+        if self._pending:
+            whole = np.concatenate([self._carry, in0]) if len(self._carry) else in0
+            whole_pos = self._carry_pos if len(self._carry) else nread
+            keep_from = max(min(o for o, _ in self._pending), whole_pos)
+            self._carry = whole[keep_from - whole_pos:].copy()
+            self._carry_pos = keep_from
+        else:
+            self._carry = np.zeros(0, dtype=np.float32)

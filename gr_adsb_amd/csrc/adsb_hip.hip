@@ -565,7 +565,7 @@ int adsb_process_mag2(adsb_ctx* c, const float* mag2_host, int64_t n, int64_t ab
   return canonical(c, 1, d, n, abs_offset, out, cap, n_out);
 }
 
-static int shard_post(adsb_ctx* c, Slot& s, const Summary& sum, int32_t nres);
+static int shard_post(adsb_ctx* c, Slot& s, const Summary& sum, int32_t nres, bool drop_overlong = false);
 
 static int submit_canonical(adsb_ctx* c, int mode, const void* d_data, int64_t n, int64_t abs_offset, int32_t* ticket) {
   if (!c || n < 1 || !ticket) return -EINVAL;
@@ -678,8 +678,10 @@ int adsb_demod_work(adsb_ctx* c, const float* in0, int64_t n, int64_t nitems_rea
 }
 
 // Halo checks of a finished shard call (the records are in the slot's pinned buffer).
-static int shard_post(adsb_ctx* c, Slot& s, const Summary& sum, int32_t nres) {
-  if (sum.flags & 4u) return fail(c, -EOVERFLOW, "pulse runs past the shard's forward halo");
+static int shard_post(adsb_ctx* c, Slot& s, const Summary& sum, int32_t nres, bool drop_overlong) {
+  // a pulse still high at the end of the buffer was left out of the result (like framer.py:102-108 leaves out a
+  // pulse still high at the end of a call): an error for exact stitching, tolerated on request
+  if ((sum.flags & 4u) && !drop_overlong) return fail(c, -EOVERFLOW, "pulse runs past the shard's forward halo");
   const Rec* r = (const Rec*)s.h_out;
   const long long origin = s.plan.origin, n = s.plan.n, stream_len = s.plan.origin + s.plan.dem_hi;
   for (int i = 0; i < nres; ++i) {
@@ -713,6 +715,23 @@ int adsb_shard_device(adsb_ctx* c, int fmt, const void* d_data, int64_t n, int64
   rc = run_pipeline(c, pl, &s, &nres);
   if (rc) return rc;
   if ((rc = shard_post(c, c->slot[c->last_slot], s, nres))) return rc;
+  return deliver(c, nres, out, cap, n_out);
+}
+
+int adsb_shard_host(adsb_ctx* c, int fmt, const void* host, int64_t n, int64_t origin, int64_t own_lo, int64_t own_hi,
+                    int64_t stream_len, int32_t head_cands, uint32_t shard_flags, adsb_burst* out, int32_t cap,
+                    int32_t* n_out) {
+  if (!c || fmt < 0 || fmt >= ADSB_FMT_COUNT || n < 1 || !host) return -EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  void* d = nullptr;
+  int rc = upload(c, host, (size_t)n * (size_t)mode_bytes(fmt), &d);
+  if (rc) return rc;
+  Plan pl;
+  if ((rc = shard_plan_checked(c, fmt, d, n, origin, own_lo, own_hi, stream_len, head_cands, &pl))) return rc;
+  Summary s;
+  int32_t nres = 0;
+  if ((rc = run_pipeline(c, pl, &s, &nres))) return rc;
+  if ((rc = shard_post(c, c->slot[c->last_slot], s, nres, (shard_flags & ADSB_SHARD_DROP_OVERLONG) != 0))) return rc;
   return deliver(c, nres, out, cap, n_out);
 }
 

@@ -81,8 +81,9 @@ def drive(framer_blk, demod_blk, x, schedule=None, demod_schedule=None):
     H = framer_blk.history()
     buf = np.concatenate([np.zeros(H - 1, dtype=np.float32), x])
     pos = 0
+    y = np.empty(L, dtype=np.float32)             # the framer's output stream: what the demod is connected to
     for N in schedule:
-        out0 = np.empty(N, dtype=np.float32)
+        out0 = y[pos:pos + N]
         framer_blk._nread = framer_blk._nwritten = pos
         assert framer_blk.work([buf[pos:pos + N + H - 1]], [out0]) == N
         pos += N
@@ -91,6 +92,6 @@ def drive(framer_blk, demod_blk, x, schedule=None, demod_schedule=None):
     for N in demod_schedule:
         out0 = np.empty(N, dtype=np.float32)
         demod_blk._nread = demod_blk._nwritten = pos
-        demod_blk.work([x[pos:pos + N]], [out0])
+        demod_blk.work([y[pos:pos + N]], [out0])
         pos += N
     return framer_blk.tags_out, demod_blk.messages

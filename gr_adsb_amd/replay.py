@@ -63,8 +63,6 @@ def replay_blocks(stream_len, sps, block_samples, shard_fn, head_cands=64, head_
 
 class FileReplay:
     def __init__(self, path, fmt, fs, threshold, block_samples=1 << 26, device=0, scale=None):
-        import torch
-        self._torch = torch
         self.fmt = FORMATS[fmt] if isinstance(fmt, str) else int(fmt)
         dt, per = _native.FMT_LAYOUT[self.fmt]
         self.items_per_sample = per
@@ -78,17 +76,12 @@ class FileReplay:
             self.ctx.set_format_scale(self.fmt, scale)
 
     def _shard(self, plan, head_cands):
-        torch = self._torch
         per = self.items_per_sample
         hi = plan["hi"]
         while True:
-            host = np.array(self.data[plan["lo"] * per:hi * per])         # private, writable copy of the file block
-            if host.dtype == np.complex64:
-                host = host.view(np.float32)
-            t = torch.from_numpy(host).to("cuda:%d" % self.device)
+            host = self.data[plan["lo"] * per:hi * per]                   # file block incl. halos -> adsb_shard_host
             try:
-                return self.ctx.shard_device(self.fmt, t.data_ptr(), hi - plan["lo"], plan["lo"], plan["own_lo"],
-                                             plan["own_hi"], self.n, head_cands)
+                return self.ctx.shard_host(self.fmt, host, plan["lo"], plan["own_lo"], plan["own_hi"], self.n, head_cands)
             except _native.AdsbError as e:
                 # -EOVERFLOW: a pulse (carrier, overlapping bursts) runs past the block's forward halo: widen it
                 if e.code != -75 or hi >= self.n:

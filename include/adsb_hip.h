@@ -189,6 +189,15 @@ int adsb_demod_work(adsb_ctx* ctx, const float* in0, int64_t n, int64_t nitems_r
 int adsb_shard_device(adsb_ctx* ctx, int fmt, const void* d_data, int64_t n, int64_t origin,
                       int64_t own_lo, int64_t own_hi, int64_t stream_len, int32_t head_cands,
                       adsb_burst* out, int32_t cap, int32_t* n_out);
+/* The same from a host buffer (uploaded like adsb_process_*): for callers that receive the stream block by block
+ * in host memory -- the chunk-invariant ("improved") GNU Radio blocks and file replay without torch.  origin may
+ * be negative when the buffer starts with the zero history in front of a fresh stream.
+ * shard_flags: ADSB_SHARD_DROP_OVERLONG = a pulse still high at the end of the buffer is left out of the result
+ * (as framer.py:102-108 leaves out a pulse still high at the end of a call) instead of failing with -EOVERFLOW. */
+#define ADSB_SHARD_DROP_OVERLONG 1u
+int adsb_shard_host(adsb_ctx* ctx, int fmt, const void* host, int64_t n, int64_t origin, int64_t own_lo,
+                    int64_t own_hi, int64_t stream_len, int32_t head_cands, uint32_t shard_flags,
+                    adsb_burst* out, int32_t cap, int32_t* n_out);
 /* eob_in = (offset of the last burst kept before this shard) + 63*sps, or a very negative number for the
  * first shard.  Compacts recs in place to the exact kept list; -EAGAIN if the head region was too short
  * (call adsb_shard_device again with a larger head_cands, or with 0 and adsb_stitch). */

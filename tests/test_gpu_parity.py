@@ -120,6 +120,48 @@ def test_dropin_blocks_match_reference_goldens(native, name, sched):
     assert all(set(m[0].keys()) == {"timestamp", "snr"} and m[1].dtype == np.uint8 and len(m[1]) == 112 for _, m in msgs)
 
 
+@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("sched", ["fixed4096", "random", "tiny"])
+def test_improved_blocks_are_chunk_invariant(native, name, sched):
+    """SURVEY.md §8f-4 (opt-in, never the parity mode): framer(improved=True) / demod(improved=True) driven with any
+    chunk schedule reproduce what the REFERENCE produces in ONE work() call over the whole stream (the golden
+    "single" vectors): no pulses lost at call boundaries, no stale gate state, no bursts dropped at chunk ends."""
+    from gr_adsb_amd import blocks, grshim
+    g = Golden(name)
+    fr = blocks.framer(g.fs, g.thr, improved=True)
+    dm = blocks.demod(g.fs, improved=True)
+    dm.start_timestamp = 0.0
+    F = fr.delay
+    assert F == 256 + 121 * g.sps and fr.history() == 100 + 8 * g.sps + 4 + F + 1
+    L = len(g.x)
+    pad = F + 4096                                   # flush the block's look-ahead
+    x = np.concatenate([g.x, np.zeros(pad, np.float32)])
+    if sched == "tiny":
+        rng = np.random.default_rng(3)
+        sch = []
+        while sum(sch) < len(x):
+            sch.append(int(min(rng.integers(1, 700), len(x) - sum(sch))))
+    else:
+        sch = g.sched(sched)
+        sch = sch + [pad]
+    tags, msgs = grshim.drive(fr, dm, x, sch)
+    want_off = g.get("single", "tag_offsets")
+    assert np.array_equal(np.array([t.value[2] for t in tags], dtype=np.int64), want_off)
+    assert np.array_equal(np.array([t.offset for t in tags], dtype=np.int64), want_off + F)       # on the delayed stream
+    snr = np.array([t.value[1] for t in tags], dtype=np.float32)
+    assert np.array_equal(snr.view(np.uint32), g.get("single", "tag_snr_bits"))
+    # PDUs: every burst the single call demodulates, bit for bit; the ones it drops at the end of the stream
+    # (eob >= L) are completed here from the zero padding and come on top
+    offs = np.array([int(round(m[0]["timestamp"] * g.fs)) for _, m in msgs], dtype=np.int64)
+    bits = np.array([m[1] for _, m in msgs], dtype=np.uint8).reshape(-1, 112)
+    inside = offs + 119 * g.sps + g.sps // 2 < L
+    assert np.array_equal(offs[inside], g.get("single", "pdu_offsets"))
+    assert np.array_equal(bits[inside], g.pdu_bits("single"))
+    assert np.array_equal(np.sort(offs), offs) and len(offs) == len(want_off)
+    psnr = np.array([m[0]["snr"] for _, m in msgs], dtype=np.float32)
+    assert np.array_equal(psnr[inside].view(np.uint32), g.get("single", "pdu_snr_bits"))
+
+
 def test_demod_confidence_bits(native):
     g = Golden("g2msps_df17")
     ctx = native.Context(g.fs, g.thr)

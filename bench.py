@@ -200,10 +200,26 @@ def main():
             n = fe.wait(pending.pop(0), fetch=False) if n_gpus == 1 else collect_shard(pending.pop(0))
         return n
 
+    # barrier / max-over-ranks go over RCCL (backend "nccl") on the GPUs; if the communicator cannot be set up on
+    # this node they fall back to the gloo side of the same process group rather than losing the run
+    sync_dev = [dev]
+    if n_gpus > 1 and not one_gpu:
+        try:
+            probe = torch.zeros(1, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+        except Exception as e:                                   # noqa: BLE001
+            if rank == 0:
+                print("bench: RCCL all_reduce failed (%s); synchronising ranks over gloo" % type(e).__name__, file=sys.stderr)
+            sync_dev[0] = "cpu"
+    elif one_gpu:
+        sync_dev[0] = "cpu"
+
     def sync_all():
-        if n_gpus > 1:
-            dist.barrier()
         torch.cuda.synchronize()
+        if n_gpus > 1:
+            dist.all_reduce(torch.zeros(1, device=sync_dev[0]))      # barrier
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -218,7 +234,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if n_gpus > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=sync_dev[0])
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     st = fe.stats()
@@ -303,7 +319,7 @@ def main():
                     "threads": nthr, "note": "same C port, one contiguous shard of the sample per host thread"}
         print(json.dumps(result), flush=True)
     if n_gpus > 1:
-        dist.barrier()
+        sync_all()
         ag_close()
         dist.destroy_process_group()
     return result

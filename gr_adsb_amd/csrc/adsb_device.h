@@ -53,6 +53,13 @@ constexpr int kAblate = ADSB_ABLATE;
 constexpr bool kNoMasks = kAblate >= 3 && kAblate < 20;   // 3, 4: streaming only; 21..24 probe the rise path
 // k_detect is latency bound per workgroup: 5 resident workgroups per CU (<= 96 VGPRs, no spills) measured
 // 15-20 % faster than 4; 6 would need spills to scratch.
+// Number of prefetch registers (of Span::ITER) reloaded inside the commit loop, right after their samples were
+// converted; the others are reloaded after the commit.  More = less time without a fetch in flight, but the
+// reloaded registers stay live through the rest of the commit (VGPR pressure: 8 costs the fifth wavefront per SIMD).
+#ifndef ADSB_EARLY_ISSUE
+#define ADSB_EARLY_ISSUE 4
+#endif
+constexpr int kEarlyIssue = ADSB_EARLY_ISSUE;
 #ifndef ADSB_MIN_WAVES
 #define ADSB_MIN_WAVES 5
 #endif
@@ -477,12 +484,19 @@ __device__ __forceinline__ void span_fill_ragged_w(float* sx, unsigned long long
 // dst = LDS sample index of the span's first sample (multiple of 64).  Every lane of the wavefront
 // must call this (ballots); a wavefront whose share is one 64-sample word (the head span) uses only
 // its low lanes for data and writes one mask word.
-template <int MODE, int COUNT, int NWAVES>
-__device__ __forceinline__ void span_commit(const Span<MODE, COUNT, NWAVES>& sp, float* sx, unsigned long long* smask,
-                                            int dst, float thr, float scale, int wave, int lane) {
+// REISSUE: `next` = address of this wavefront's share of the NEXT span (entirely inside the buffer); every
+// register is loaded again the moment its samples have been converted, so the only time a wavefront has no
+// fetch in flight is one |IQ|^2 computation per register -- not the whole commit (LDS writes, ballots, mask
+// interleave), which now runs under the next tile's loads.
+template <int MODE, int COUNT, int NWAVES, int REISSUE = 0>
+__device__ __forceinline__ void span_commit(Span<MODE, COUNT, NWAVES>& sp, float* sx, unsigned long long* smask,
+                                            int dst, float thr, float scale, int wave, int lane,
+                                            const char* next = nullptr) {
   using S = Span<MODE, COUNT, NWAVES>;
+  using Q = typename S::Q;
   const int wdst = dst + wave * S::SHARE;
   const bool act = (S::LANES == 64) || lane < S::LANES;
+  const unsigned lo = (unsigned)lane * (unsigned)sizeof(Q);
 #pragma unroll
   for (int k = 0; k < S::ITER; ++k) {
     const int g = wdst + k * S::GROUP;                        // first LDS sample of this wave-wide group
@@ -490,6 +504,7 @@ __device__ __forceinline__ void span_commit(const Span<MODE, COUNT, NWAVES>& sp,
       float2 m;
       m.x = mag2f(sp.q[k].x, sp.q[k].y);
       m.y = mag2f(sp.q[k].z, sp.q[k].w);
+      if (REISSUE > 0 && k < REISSUE) sp.q[k] = *reinterpret_cast<const Q*>(next + (k * 64 * (int)sizeof(Q) + lo));
       if (act) *reinterpret_cast<float2*>(&sx[g + 2 * lane]) = m;
       if (!kNoMasks) {
         // lane l holds samples 2l, 2l+1: the even/odd threshold masks (framer.py:83-84) are interleaved into
@@ -521,6 +536,7 @@ __device__ __forceinline__ void span_commit(const Span<MODE, COUNT, NWAVES>& sp,
       } else {
         m = sp.q[k];
       }
+      if (REISSUE > 0 && k < REISSUE) sp.q[k] = *reinterpret_cast<const Q*>(next + (k * 64 * (int)sizeof(Q) + lo));
       if (act) *reinterpret_cast<float4*>(&sx[g + 4 * lane]) = m;
       if (!kNoMasks) {
         const unsigned long long A = __ballot(act && m.x >= thr), B = __ballot(act && m.y >= thr);
@@ -538,6 +554,10 @@ __device__ __forceinline__ void span_commit(const Span<MODE, COUNT, NWAVES>& sp,
         }
       }
     }
+  }
+  if constexpr (REISSUE > 0) {                               // the registers consumed last are reloaded last
+#pragma unroll
+    for (int k = REISSUE; k < S::ITER; ++k) sp.q[k] = *reinterpret_cast<const Q*>(next + (k * 64 * (int)sizeof(Q) + lo));
   }
 }
 
@@ -594,9 +614,17 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
 
   for (long long t0 = c0; t0 < c1; t0 += kWTile) {
     // -- A: commit this tile's body (floats + mask words 4..19), start fetching the next one
-    if (!body_ok) span_fill_ragged_w<MODE, kWTile>(s_x, s_mask, kFwd, a, t0 + kFwd, lane);
-    else span_commit(body, s_x, s_mask, kFwd, a.thr, a.scale, 0, lane);
-    if (t0 + kWTile < c1) body_ok = span_issue(body, a, t0 + kWTile + kFwd, 0, lane);
+    if (!body_ok) {
+      span_fill_ragged_w<MODE, kWTile>(s_x, s_mask, kFwd, a, t0 + kFwd, lane);
+      if (t0 + kWTile < c1) body_ok = span_issue(body, a, t0 + kWTile + kFwd, 0, lane);
+    } else if (kEarlyIssue > 0 && t0 + kWTile < c1 && t0 + 2 * kWTile + kFwd <= a.n) {
+      // the usual case: the next tile's body lies inside the buffer -> reload every register as soon as it is consumed
+      const char* nb = reinterpret_cast<const char*>(a.data) + (t0 + kWTile + kFwd) * (long long)mode_bytes(MODE);
+      span_commit<MODE, kWTile, 1, kEarlyIssue>(body, s_x, s_mask, kFwd, a.thr, a.scale, 0, lane, nb);
+    } else {
+      span_commit(body, s_x, s_mask, kFwd, a.thr, a.scale, 0, lane);
+      if (t0 + kWTile < c1) body_ok = span_issue(body, a, t0 + kWTile + kFwd, 0, lane);
+    }
     adsb_wave_sync();
 
     // -- B.1 rises / falls by mask algebra (framer.py:91-93); lanes 0..15 own one word each

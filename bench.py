@@ -312,6 +312,17 @@ def main():
                           "the reference path incl. |IQ|^2), best of 5 (about 6 s of CPU work), host has %d cpus" % (int(np.log2(n_cpu)), os.cpu_count()),
             }
             result["bit_match"] = {"sample_bursts": int(len(crecs)), "identical": bool(match)}
+            # the reference-STRUCTURED restatement (vectorised threshold/edges + per-pulse Python
+            # loop, oracle/adsb_oracle.py) on one core, next to the scalar C port above
+            from oracle import adsb_oracle as O
+            n_np = min(n_cpu, 1 << 24)
+            t_np = time.perf_counter()
+            o_np = O.run_stream(O.mag2(host[:n_np]), fs, args.threshold)
+            t_np = time.perf_counter() - t_np
+            result["cpu_baseline"]["numpy_port"] = {
+                "value": round(n_np / t_np / 1e6, 1), "unit": "Msamples/s", "cores": 1,
+                "sample": "first 2^%d samples, oracle/adsb_oracle.py (NumPy restatement with the reference's structure), %d tags"
+                          % (int(np.log2(n_np)), len(o_np["tag_offsets"]))}
             nthr = min(64, os.cpu_count() or 1)
             if nthr > 1:
                 result["cpu_baseline"]["all_threads"] = {

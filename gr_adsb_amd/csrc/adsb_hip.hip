@@ -246,7 +246,9 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   if ((r = ensure(c, s.d_long, (size_t)long_cap * sizeof(LongRise)))) return r;
   if (!s.d_misc.p) {
     if ((r = ensure(c, s.d_misc, sizeof(Misc)))) return r;
-    HIPCHK(c, hipMemset(s.d_misc.p, 0, sizeof(Misc)));   // afterwards k_scan2 re-zeroes the list head every pass
+    // on the compute stream (the context's streams are non-blocking: a legacy-stream memset would not be ordered
+    // before the first k_detect); afterwards k_scan2 re-zeroes the list head every pass
+    HIPCHK(c, hipMemsetAsync(s.d_misc.p, 0, sizeof(Misc), c->stream));
   }
   Misc* misc = (Misc*)s.d_misc.p;
 

@@ -527,6 +527,32 @@ def test_caller_stream_and_reset(native, torch_mod):
     assert np.array_equal(a, o["tag_offsets"]) and np.array_equal(b, a) and len(a) > 50
 
 
+def test_contexts_are_independent_across_threads(native):
+    """a context is single-threaded, different contexts run concurrently (one per GR block / per
+    stream).  Six host threads, each with its own context, sample rate and data, hammering the library at once."""
+    from concurrent.futures import ThreadPoolExecutor
+    from gr_adsb_amd import modulator as M
+    from oracle import c_oracle as C
+    cases = [(2e6, 3000, 1), (4e6, 3000, 2), (8e6, 6000, 3), (20e6, 2000, 4), (2e6, 20000, 5), (8e6, 500, 6)]
+    data = [(fs, M.synth_iq(1 << 19, fs, bps, seed)) for fs, bps, seed in cases]
+    want = [C.process_iq(iq, int(fs // 1e6), 0.01) for fs, iq in data]
+
+    def worker(i):
+        fs, iq = data[i]
+        ctx = native.Context(fs, 0.01)
+        outs = [ctx.process_iq(iq) for _ in range(20)]
+        x = M.mag2(iq)
+        outs.append(ctx.process_mag2(x))
+        return outs
+
+    with ThreadPoolExecutor(max_workers=len(cases)) as ex:
+        res = list(ex.map(worker, range(len(cases))))
+    for i, outs in enumerate(res):
+        assert len(want[i]) > 10
+        for o in outs:
+            assert_recs_equal(o, want[i], "thread %d" % i)
+
+
 def test_adversarial_streams(native):
     """The seam-hunting streams of test_sim_property.py (plateaus and bursts planted on tile / window
     boundaries, exact ties, thresholds on sample values, NaNs) through the real kernels."""

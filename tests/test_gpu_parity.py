@@ -553,6 +553,50 @@ def test_contexts_are_independent_across_threads(native):
             assert_recs_equal(o, want[i], "thread %d" % i)
 
 
+def test_lifecycle_stress(native, torch_mod):
+    """Create/destroy many contexts, sizes growing and shrinking, every entry point interleaved on one context:
+    results stay exact and device memory returns to where it started."""
+    torch = torch_mod
+    from gr_adsb_amd import modulator as M
+    from oracle import adsb_oracle as O
+    from oracle import c_oracle as C
+    fs, sps = 2e6, 2
+    big = M.synth_iq(1 << 21, fs, 4000, 61)
+    sizes = [1 << 21, 1000, 1 << 18, 77, 1 << 20, 5, 1 << 21, 1 << 12]
+    want = {n: C.process_iq(big[:n], sps, 0.01) for n in sizes}
+    free = []
+    for rep in range(31):
+        ctx = native.Context(fs, 0.01)
+        for n in (sizes if rep % 5 == 0 else sizes[rep % len(sizes):][:2]):
+            assert_recs_equal(ctx.process_iq(big[:n]), want[n], "rep %d n %d" % (rep, n))
+        ctx.close()
+        del ctx
+        torch.cuda.synchronize()
+        free.append(torch.cuda.mem_get_info()[0])
+    # after the first lifecycles (runtime pools, code objects) free device memory must not keep shrinking
+    assert free[10] - free[30] < (16 << 20), [(f - free[0]) >> 20 for f in free]
+    # one context, every kind of call interleaved
+    ctx = native.Context(fs, 0.01)
+    dev = to_dev(torch, big)
+    x = O.mag2(big[:1 << 16])
+    o = O.run_stream(x, fs, 0.01, [8192] * 8)
+    H = 8 * sps
+    pad = np.concatenate([np.zeros(H - 1, np.float32), x])
+    tags, pos = [], 0
+    for k in range(8):
+        tags.append(ctx.framer_work(pad[pos:pos + 8192 + H - 1], 8192, pos)["offset"].copy())      # stateful GR call ...
+        pos += 8192
+        n = sizes[k]
+        assert_recs_equal(ctx.process_iq(big[:n]), want[n], "interleaved host")                     # ... canonical calls between
+        t = ctx.submit_iq_device(dev.data_ptr(), 1 << 21)
+        bits, ok, _ = ctx.demod_work(x, 0, o["pdu_offsets"][:10])
+        assert ok.all() and np.array_equal(bits, o["pdu_bits"][:10])
+        assert_recs_equal(ctx.wait(t), want[1 << 21], "interleaved submit")
+    assert np.array_equal(np.concatenate(tags), o["tag_offsets"])              # the framer state survived all of it
+    with pytest.raises(native.AdsbError):
+        ctx.wait(0)                                                            # nothing pending
+
+
 def test_adversarial_streams(native):
     """The seam-hunting streams of test_sim_property.py (plateaus and bursts planted on tile / window
     boundaries, exact ties, thresholds on sample values, NaNs) through the real kernels."""

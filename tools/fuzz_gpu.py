@@ -24,6 +24,7 @@ def main():
     ctxs = {}
     t0 = time.time()
     n_cases = n_bursts = 0
+    n_gr = [0]
     sizes = [1, 17, 240, 1023, 1024, 1025, 1279, 1280, 1281, 4095, 4096, 4097, 4111, 4352, 8191, 8192, 8193, 12288, 20000,
              70000, 300001, 1 << 20, (1 << 22) + 5, 6_000_000]
     while time.time() - t0 < budget:
@@ -58,10 +59,25 @@ def main():
             if parts is not None:
                 got = np.concatenate(parts) if parts else np.zeros(0, _native.BURST_DTYPE)
                 assert_recs_equal(got, want, what + " replay %d" % blk)
+        if 240 <= n <= 20000 and rng.random() < 0.3:  # GNU Radio emulation: random chunk schedule vs the NumPy oracle
+            from gr_adsb_amd import blocks, grshim
+            sch = []
+            while sum(sch) < n:
+                sch.append(int(min(rng.choice([1, 7, 100, 700, 4096, 9000]), n - sum(sch))))
+            fr, dm = blocks.framer(sps * 1e6, thr), blocks.demod(sps * 1e6)
+            dm.start_timestamp = 0.0
+            tags, msgs = grshim.drive(fr, dm, x, sch)
+            o = O.run_stream(x, sps * 1e6, thr, sch)
+            assert np.array_equal(np.array([t.offset for t in tags], dtype=np.int64), o["tag_offsets"]), what + " gr tags"
+            snr = np.array([t.value[1] for t in tags], dtype=np.float32)
+            assert np.array_equal(snr.view(np.uint32), o["tag_snr"].view(np.uint32)), what + " gr snr"
+            bits = np.array([m[1] for _, m in msgs], dtype=np.uint8).reshape(-1, 112)
+            assert np.array_equal(bits, o["pdu_bits"]), what + " gr pdus"
+            n_gr[0] += 1
         n_cases += 1
         n_bursts += len(want)
         seed += 1
-    print("fuzz: %d cases, %d bursts, seeds up to %d, %.0f s: all identical" % (n_cases, n_bursts, seed - 1, time.time() - t0))
+    print("fuzz: %d cases (%d with a GNU Radio chunk schedule), %d bursts, seeds up to %d, %.0f s: all identical" % (n_cases, n_gr[0], n_bursts, seed - 1, time.time() - t0))
 
 
 if __name__ == "__main__":

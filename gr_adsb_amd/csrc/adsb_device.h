@@ -3,7 +3,7 @@
 //   k_detect   streams the IQ once: |IQ|^2 -> threshold bitmask (one __ballot per 64 samples) -> rises by
 //              mask algebra -> pulse centre -> 16-chip preamble test; emits matched centres per wavefront
 //   k_longrun  (rare) pulses longer than the LDS window
-//   k_scan / k_gather / k_resolve / k_count / k_scan2 / k_compact
+//   k_scan / k_gather / k_resolve / k_count / k_compact
 //              order the centres, apply the re-trigger gate as parallel chain walks, compact
 //   k_burst    one wavefront per surviving centre: peak, median-of-100 noise, 112-bit PPM slice
 //   k_slice    PPM slice for a caller-supplied tag list (the stand-alone demod block)
@@ -869,6 +869,9 @@ __global__ void __launch_bounds__(kThreads) k_scan(const int* blk_count, const l
   const int b0 = tid * per;
   int b1 = b0 + per; if (b1 > nblk) b1 = nblk;
   int acc = 0; long long lp = kNoIndex; unsigned fl = 0;
+  // (the lists of a thread are independent: unrolled so that a thread's loads are in flight together -- this kernel
+  // is a latency chain on the tail of every pass)
+#pragma unroll 8
   for (int b = b0; b < b1; ++b) {
     int c = blk_count[b];
     if (c > rec_cap) { fl |= 0x80000000u; c = rec_cap; }      // bit 31: some workgroup overflowed its list
@@ -895,6 +898,7 @@ __global__ void __launch_bounds__(kThreads) k_scan(const int* blk_count, const l
     sum->n_rec = total; sum->overflow = (F >> 31) & 1u; sum->flags = F & 0x7FFFFFFFu; sum->lastp = L;
     sum->long_count = *long_count; sum->n_kept = 0; sum->last_kept_p = kNoIndex;
   }
+#pragma unroll 8
   for (int b = b0; b < b1; ++b) {
     int c = blk_count[b];
     if (c > rec_cap) c = rec_cap;
@@ -956,7 +960,7 @@ __global__ void __launch_bounds__(kThreads) k_resolve(unsigned long long* sorted
   }
 }
 
-// ---- k_count / k_scan2 / k_compact: survivors -> dense list ------------------------------------------
+// ---- k_count / k_compact: survivors -> dense list ---------------------------------------------------
 // A real centre survives when (flags & fmask) == fwant -- gate on: (kKept, kKept); gate off: (0, 0) -- or
 // when it is one of the first head_n entries of the list (shard mode: the head of a shard is delivered
 // whole so that the host can re-gate it against the previous shard's tail).
@@ -983,48 +987,47 @@ __global__ void __launch_bounds__(kThreads) k_count(const unsigned long long* so
   }
 }
 
-__global__ void __launch_bounds__(kThreads) k_scan2(int* seg_count, Summary* sum, int* long_count,
-                                                    unsigned long long* long_lastp) {
-  // exclusive scan of seg_count in place (single workgroup) + total
-  const int n = sum->n_rec;
-  const int nseg = (n + kThreads - 1) / kThreads;
-  const int tid = threadIdx.x;
-  const int per = (nseg + kThreads - 1) / kThreads;
-  const int b0 = tid * per;
-  int b1 = b0 + per; if (b1 > nseg) b1 = nseg;
-  int acc = 0;
-  for (int b = b0; b < b1; ++b) acc += seg_count[b];
-  int total = 0;
-  int run = block_excl_scan(acc, &total);
-  if (tid == 0) {
-    sum->n_kept = total;
-    *long_count = 0;        // k_scan has consumed the long-pulse list: leave it empty for the slot's next pass
-    *long_lastp = 0ull;
-  }
-  for (int b = b0; b < b1; ++b) { const int c = seg_count[b]; seg_count[b] = run; run += c; }
-}
-
+// k_compact also does what a separate single-workgroup scan kernel used to: every workgroup sums the segment counts
+// in front of its segment itself (a few hundred ints, L2 resident) -- one launch fewer on the tail of every pass.
 __global__ void __launch_bounds__(kThreads) k_compact(const unsigned long long* sorted, Summary* sum,
-                                                      const int* seg_off, unsigned fmask, unsigned fwant, int head_n,
-                                                      unsigned long long* kept, int out_cap) {
+                                                      const int* seg_count, unsigned fmask, unsigned fwant, int head_n,
+                                                      unsigned long long* kept, int out_cap, int* long_count,
+                                                      unsigned long long* long_lastp) {
   __shared__ int s_c[kWaves];
+  __shared__ int s_pre[kWaves], s_tot[kWaves];
   const int n = sum->n_rec;
   const int nseg = (n + kThreads - 1) / kThreads;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *long_count = 0;        // k_scan has consumed the long-pulse list: leave it empty for the slot's next pass
+    *long_lastp = 0ull;
+    if (nseg == 0) sum->n_kept = 0;
+  }
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    // exclusive prefix of this segment and the grand total
+    int pre = 0, tot = 0;
+    for (int j = threadIdx.x; j < nseg; j += kThreads) {
+      const int cj = seg_count[j];
+      tot += cj;
+      if (j < seg) pre += cj;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { pre += __shfl_xor(pre, d); tot += __shfl_xor(tot, d); }
     const int i = seg * kThreads + threadIdx.x;
     unsigned long long c = (i < n) ? sorted[i] : 0ull;
     const bool k = i < n && survives(c, i, fmask, fwant, head_n);
     if (i < head_n) c |= (unsigned long long)kHead << 56;
     const unsigned long long m = __ballot(k);
-    if (lane == 0) s_c[wave] = __popcll(m);
+    if (lane == 0) { s_c[wave] = __popcll(m); s_pre[wave] = pre; s_tot[wave] = tot; }
     __syncthreads();
-    int off = seg_off[seg];
+    int off = s_pre[0] + s_pre[1] + s_pre[2] + s_pre[3];
+    const int total = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
     for (int w = 0; w < wave; ++w) off += s_c[w];
     off += lanes_below(m, lane);
+    if (seg == 0 && threadIdx.x == 0) sum->n_kept = total;
     if (k && off < out_cap) {
       kept[off] = c;
-      if (off == sum->n_kept - 1) sum->last_kept_p = cand_p(c);
+      if (off == total - 1) sum->last_kept_p = cand_p(c);
     }
     __syncthreads();
   }
@@ -1033,10 +1036,13 @@ __global__ void __launch_bounds__(kThreads) k_compact(const unsigned long long* 
 // ---- k_burst: one wavefront per surviving centre -> the 32-byte burst record -------------------------
 template <int MODE>
 __global__ void __launch_bounds__(kThreads) k_burst(DetectArgs a, const unsigned long long* kept, const Summary* sum,
-                                                    Rec* out, int out_cap) {
+                                                    Rec* out, int out_cap, Summary* host_sum) {
   const int lane = threadIdx.x & 63;
   const int wave_g = (int)((blockIdx.x * (unsigned)kThreads + threadIdx.x) >> 6);
   const int nwave = (int)((gridDim.x * (unsigned)kThreads) >> 6);
+  // the pass's 48-byte summary is final before this kernel starts: one thread stores it straight into the caller-
+  // visible (pinned, mapped) host copy -- no separate copy operation on the tail of the pass
+  if (host_sum != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *host_sum = *sum;
   int n = sum->n_kept;
   if (n > out_cap) n = out_cap;
   const ParityConsts pc = parity_consts(lane);

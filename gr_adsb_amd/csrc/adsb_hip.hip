@@ -1,6 +1,6 @@
 // adsb_hip.hip -- host side of libadsb_hip.so (C ABI in include/adsb_hip.h) for gfx950.
 // Owns device memory, pinned staging and the launch sequence
-//   k_detect -> k_scan -> k_gather -> k_resolve -> k_count -> k_scan2 -> k_compact -> k_burst  (+ k_longrun when needed)
+//   k_detect -> k_scan -> k_gather -> k_resolve -> k_count -> k_compact -> k_burst  (+ k_longrun when needed)
 // There is deliberately no CPU implementation of the path in this library.
 #include <hip/hip_runtime.h>
 
@@ -158,12 +158,23 @@ int detect_occupancy() {
 }
 template <int MODE>
 void launch_burst(adsb_ctx* c, hipStream_t st, const DetectArgs& a, const unsigned long long* kept, const Summary* sum,
-                  Rec* out, int cap) {
-  hipLaunchKernelGGL((k_burst<MODE>), dim3(c->n_cu * 8), dim3(kThreads), 0, st, a, kept, sum, out, cap);
+                  Rec* out, int cap, Summary* host_sum) {
+  hipLaunchKernelGGL((k_burst<MODE>), dim3(c->n_cu * 8), dim3(kThreads), 0, st, a, kept, sum, out, cap, host_sum);
 }
 template <int MODE>
 void launch_longrun(hipStream_t st, const DetectArgs& a) {
   hipLaunchKernelGGL((k_longrun<MODE>), dim3(64), dim3(kThreads), 0, st, a);
+}
+
+// tuning probe (ADSB_DEBUG_DUMMY=<blocks>,<microseconds>): a kernel that only spins, in place of the tail
+__global__ void k_dummy(long long ticks, const int* rd, int* wr, int mode) {
+  const long long t0 = wall_clock64();
+  int acc = 0;
+  while (wall_clock64() - t0 < ticks) {
+    __builtin_amdgcn_s_sleep(8);
+    if (mode & 1) acc += __builtin_nontemporal_load(rd + ((threadIdx.x * 16 + (int)(wall_clock64() & 1023)) % 5000));
+  }
+  if ((mode & 2) || acc == 0x7fffffff) wr[threadIdx.x] = acc;
 }
 
 // Everything after k_detect (and after k_longrun on the rare second pass): order, gate, compact, records.
@@ -182,30 +193,40 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
     HIPCHK(c, hipStreamWaitEvent(c->tail_stream, dep, 0));
     ts = c->tail_stream;
   }
+  // tuning probe ADSB_DEBUG_TAIL_MASK: launch only the tail stages whose bit is set (results are garbage then):
+  // 1 longrun, 2 scan, 4 gather, 8 resolve, 16 count, 64 compact, 128 burst, 256 summary copy
+  static const unsigned tm = getenv("ADSB_DEBUG_TAIL_MASK") ? (unsigned)strtoul(getenv("ADSB_DEBUG_TAIL_MASK"), nullptr, 0) : ~0u;
+  static const char* dummy = getenv("ADSB_DEBUG_DUMMY");
+  if (dummy) {
+    int nb = 1, us = 100, mode = 0;
+    sscanf(dummy, "%d,%d,%d", &nb, &us, &mode);
+    hipLaunchKernelGGL(k_dummy, dim3(nb), dim3(kThreads), 0, ts, (long long)us * 100, (const int*)a.blk_count,
+                       (int*)s.d_blk_off.p, mode);   // wall clock: 100 MHz
+  }
   // no-op unless k_detect listed pulses longer than its LDS window
-  ADSB_BY_MODE(pl.mode, launch_longrun, ts, a);
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(kThreads), 0, ts, (const int*)a.blk_count,
+  if (tm & 1) ADSB_BY_MODE(pl.mode, launch_longrun, ts, a);
+  if (tm & 2) hipLaunchKernelGGL(k_scan, dim3(1), dim3(kThreads), 0, ts, (const int*)a.blk_count,
                      (const long long*)a.blk_lastp, (const unsigned*)a.blk_flags, s.nlists, s.rec_cap,
                      (const int*)a.long_count, (const unsigned long long*)a.long_lastp, (int*)s.d_blk_off.p, &misc->sum);
   const int gg = s.nlists < 1024 ? s.nlists : 1024;
   unsigned long long* sorted = (unsigned long long*)s.d_sorted.p;
   unsigned long long* kept = (unsigned long long*)s.d_kept.p;
-  hipLaunchKernelGGL(k_gather, dim3(gg), dim3(kThreads), 0, ts, (const unsigned long long*)a.cands,
+  if (tm & 4) hipLaunchKernelGGL(k_gather, dim3(gg), dim3(kThreads), 0, ts, (const unsigned long long*)a.cands,
                      (const int*)a.blk_count, (const int*)s.d_blk_off.p, s.nlists, s.rec_cap, sorted);
   const int ag = 512;
   unsigned fmask = 0u, fwant = 0u;
   if (pl.gate) {
-    hipLaunchKernelGGL(k_resolve, dim3(ag), dim3(kThreads), 0, ts, sorted, (const Summary*)&misc->sum,
+    if (tm & 8) hipLaunchKernelGGL(k_resolve, dim3(ag), dim3(kThreads), 0, ts, sorted, (const Summary*)&misc->sum,
                        (long long)63 * c->sps, pl.prev_eob_stream - pl.origin);
     fmask = kKept; fwant = kKept;
   }
-  hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted,
+  if (tm & 16) hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted,
                      (const Summary*)&misc->sum, fmask, fwant, pl.head_n, (int*)s.d_seg.p);
-  hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kThreads), 0, ts, (int*)s.d_seg.p, &misc->sum, a.long_count, a.long_lastp);
-  hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted, &misc->sum,
-                     (const int*)s.d_seg.p, fmask, fwant, pl.head_n, kept, (int)s.tot);
-  ADSB_BY_MODE(pl.mode, launch_burst, c, ts, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot);
-  HIPCHK(c, hipMemcpyAsync(s.h_sum, &misc->sum, sizeof(Summary), hipMemcpyDeviceToHost, ts));
+  if (tm & 64) hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted, &misc->sum,
+                     (const int*)s.d_seg.p, fmask, fwant, pl.head_n, kept, (int)s.tot, a.long_count, a.long_lastp);
+  // k_burst also stores the summary into s.h_sum (pinned host memory, device-visible): visible to the host once
+  // the `done` event below has completed
+  if (tm & 128) ADSB_BY_MODE(pl.mode, launch_burst, c, ts, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot, s.h_sum);
   HIPCHK(c, hipEventRecord(s.done, ts));
   return 0;
 }
@@ -222,7 +243,8 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   long long ntiles = (s.span + tile - 1) / tile;
   if (ntiles < 1) ntiles = 1;
   static const int bpc_env = getenv("ADSB_DEBUG_BPC") ? atoi(getenv("ADSB_DEBUG_BPC")) : 0;
-  const long long umax = (long long)c->n_cu * (bpc_env > 0 ? bpc_env : c->bpc[pl.mode]) * upb;
+  static const int slack_env = getenv("ADSB_DEBUG_GRID_SLACK") ? atoi(getenv("ADSB_DEBUG_GRID_SLACK")) : 0;   // tuning probe
+  const long long umax = ((long long)c->n_cu * (bpc_env > 0 ? bpc_env : c->bpc[pl.mode]) - slack_env) * upb;
   long long units = ntiles < umax ? ntiles : umax;
   const long long tiles_per = (ntiles + units - 1) / units;
   units = (ntiles + tiles_per - 1) / tiles_per;
@@ -247,7 +269,7 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   if (!s.d_misc.p) {
     if ((r = ensure(c, s.d_misc, sizeof(Misc)))) return r;
     // on the compute stream (the context's streams are non-blocking: a legacy-stream memset would not be ordered
-    // before the first k_detect); afterwards k_scan2 re-zeroes the list head every pass
+    // before the first k_detect); afterwards k_compact re-zeroes the list head every pass
     HIPCHK(c, hipMemsetAsync(s.d_misc.p, 0, sizeof(Misc), c->stream));
   }
   Misc* misc = (Misc*)s.d_misc.p;
@@ -313,7 +335,8 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
     const int nres = sum->n_kept;
     int r = ensure_pinned(c, s.h_out, s.h_out_cap, (size_t)(nres > 0 ? nres : 1) * sizeof(Rec));
     if (r) { s.busy = false; return r; }
-    if (nres > 0) {
+    static const bool skip_d2h = getenv("ADSB_DEBUG_SKIP_D2H") != nullptr;   // tuning probe: records are not delivered
+    if (nres > 0 && !skip_d2h) {
       HIPCHK(c, hipMemcpyAsync(s.h_out, s.d_out.p, (size_t)nres * sizeof(Rec), hipMemcpyDeviceToHost, c->copy_stream));
       HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     }

@@ -89,10 +89,9 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     }
     hipsim::launch(k_count, 3, kThreads, (const unsigned long long*)sorted.data(), (const Summary*)&sum, fmask, fwant,
                    head_n, seg.data());
-    hipsim::launch(k_scan2, 1, kThreads, seg.data(), &sum, &long_count, &long_lastp);
     hipsim::launch(k_compact, 3, kThreads, (const unsigned long long*)sorted.data(), &sum, (const int*)seg.data(),
-                   fmask, fwant, head_n, kept.data(), (int)tot);
-    SIM_BY_MODE(mode, k_burst, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum, outv.data(), (int)tot);
+                   fmask, fwant, head_n, kept.data(), (int)tot, &long_count, &long_lastp);
+    SIM_BY_MODE(mode, k_burst, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum, outv.data(), (int)tot, (Summary*)nullptr);
   }
   so->n_rec = sum.n_rec; so->n_kept = sum.n_kept; so->overflow = sum.overflow; so->long_count = sum.long_count;
   so->flags = sum.flags; so->lastp = sum.lastp; so->last_kept = sum.last_kept_p;

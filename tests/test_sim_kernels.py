@@ -224,3 +224,13 @@ def test_replay_blocks_equal_one_canonical_call(bps, block, head, growth, monkey
     want = C.canonical(O.mag2(iq), sps, np.float32(0.01))
     assert_recs_equal(got, want, "replay")
     assert np.all((got["flags"] & 2) != 0) and not np.any(got["flags"] & 16)
+
+
+def test_many_units():
+    """A grid of 40 workgroups = 160 per-wavefront lists: ordering across many units (k_scan / k_gather)."""
+    fs, n = 2e6, 170_000
+    iq = M.synth_iq(n, fs, 8000, seed=33)
+    recs, so = simlib.sim_canonical(0, iq, fs, 0.01, grid_max=40)
+    assert so.overflow == 0
+    assert_recs_equal(recs, C.canonical(O.mag2(iq), 2, np.float32(0.01)), "160 lists")
+    assert len(recs) > 200

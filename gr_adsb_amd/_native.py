@@ -15,6 +15,7 @@ BURST_DTYPE = np.dtype([("offset", "<i8"), ("peak", "<f4"), ("median", "<f4"), (
 assert BURST_DTYPE.itemsize == 32
 
 FLAG_TIMING = 1
+FLAG_LONG_AWARE_GATE = 2  # opt-in: the gate holds 119*sps after a burst whose first data bit is set
 # input sample formats (include/adsb_hip.h ADSB_FMT_*): numpy dtype of the flat host array, items per sample
 FMT_FC32, FMT_MAG2, FMT_SC16, FMT_SC8, FMT_CU8 = 0, 1, 2, 3, 4
 FMT_LAYOUT = {FMT_FC32: (np.complex64, 1), FMT_MAG2: (np.float32, 1), FMT_SC16: (np.int16, 2), FMT_SC8: (np.int8, 2),
@@ -26,6 +27,7 @@ BURST_PARITY_OK = 32     # Mode S parity pre-filter bits (include/adsb_hip.h; de
 BURST_LONG = 64
 BURST_KNOWN_DF = 128
 BURST_DF_SHIFT = 8
+BURST_LONG_HINT = 0x2000 # records of a long-aware context: this burst holds the gate for 119*sps
 MAX_IN_FLIGHT = 3
 
 EXPORTS = [
@@ -362,6 +364,12 @@ def shard_fixup(recs, sps, eob_in, inplace=False):
 SYNC_ALWAYS = (1 << 62)
 
 
+def gate_window(recs, sps):
+    """Samples the re-trigger gate stays closed after each burst: 63*sps (framer.py:165), 119*sps for records a
+    long-aware context flagged BURST_LONG_HINT."""
+    return np.where((recs["flags"] & BURST_LONG_HINT) != 0, 119, 63).astype(np.int64) * int(sps)
+
+
 def shard_head_sync(recs, sps):
     """What decides -- for ANY incoming eob -- whether shard_fixup can succeed on this shard: the largest offset
     of a head-region centre that lies more than 63*sps after its predecessor (fixup succeeds iff that offset is
@@ -372,7 +380,8 @@ def shard_head_sync(recs, sps):
     if nh == len(recs):
         return SYNC_ALWAYS
     off = recs["offset"][:nh]
-    idx = np.flatnonzero(np.diff(off) > 63 * sps)
+    reach = np.maximum.accumulate(off + gate_window(recs[:nh], sps))      # how far the centres so far can hold the gate
+    idx = np.flatnonzero(off[1:] > reach[:-1])
     return int(off[idx[-1] + 1]) if len(idx) else EOB_NONE
 
 
@@ -381,7 +390,7 @@ def shard_tail(recs, sps):
     fl = recs["flags"]
     for i in range(len(recs) - 1, -1, -1):          # behind the head region every record is KEPT: O(1) in practice
         if fl[i] & BURST_KEPT:
-            return int(recs["offset"][i]) + 63 * sps
+            return int(recs["offset"][i]) + (119 if fl[i] & BURST_LONG_HINT else 63) * sps
     return EOB_NONE
 
 

@@ -40,16 +40,21 @@ def make_pdu(start_timestamp, fs, offset, snr, bits112):
 class framer(gr.sync_block):
     """ADS-B preamble detector / tagger (reference python/adsb/framer.py:33-182)."""
 
-    def __init__(self, fs, threshold, device=0, improved=False):
+    def __init__(self, fs, threshold, device=0, improved=False, long_aware=False):
         """improved (extension; default off = the reference's behaviour bit for bit): the tags no
         longer depend on how the scheduler chunks the stream -- pulses straddling a work() boundary are evaluated
         (framer.py:98-108 drops them), the re-trigger state never goes stale (framer.py:177-179) -- and equal those of
         ONE reference work() call over the whole stream.  Price: the block delays its output by `self.delay` samples
         (256 + 121*sps: the look-ahead a complete pulse + burst needs), so that every tag lands on a sample it has
         not produced yet; tag values become ("SOB", snr, input_offset).  Pulses longer than 256 samples are not
-        evaluated."""
+        evaluated.  long_aware (needs improved): the gate additionally holds for the whole length of a 112-bit reply
+        (first data bit set) instead of always assuming a short one (framer.py:163-165) -- fewer false tags inside long
+        replies; this changes the tag set itself, not just its chunk dependence."""
         gr.sync_block.__init__(self, name="ADS-B Framer", in_sig=[np.float32], out_sig=[np.float32])
         self.improved = bool(improved)
+        if long_aware and not improved:
+            raise ValueError("long_aware needs improved=True (the reference-exact mode keeps the reference's gate)")
+        self.long_aware = bool(long_aware)
         self.fs = fs
         assert self.fs % SYMBOL_RATE == 0, \
             "ADS-B Framer is designed to operate on an integer number of samples per symbol, not %f sps" % (self.fs / SYMBOL_RATE)
@@ -67,7 +72,8 @@ class framer(gr.sync_block):
             self._eob = _native.EOB_NONE                  # end-of-burst state carried between calls (stream offsets)
         self.set_history(self.N_hist)
         self.set_tag_propagation_policy(gr.TPP_ONE_TO_ONE)
-        self._ctx = _native.Context(fs, threshold, device=device)
+        self._ctx = _native.Context(fs, threshold, device=device,
+                                    flags=_native.FLAG_LONG_AWARE_GATE if self.long_aware else 0)
 
     def set_threshold(self, threshold):
         self.threshold = threshold            # read once per work(), like the reference (framer.py:84)
@@ -98,7 +104,7 @@ class framer(gr.sync_block):
             kept = greedy_gate(self._ctx.shard_host(_native.FMT_MAG2, buf, origin, own_lo, own_hi, _native.STREAM_UNBOUNDED,
                                                     head_cands=0, drop_overlong=True), self.sps, self._eob)
         if len(kept):
-            self._eob = int(kept["offset"][-1]) + 63 * self.sps
+            self._eob = int(kept["offset"][-1]) + int(_native.gate_window(kept[-1:], self.sps)[0])
         snr = _native.snr_db(kept["peak"], kept["median"])
         for b, s_ in zip(kept, snr):
             off = int(b["offset"])

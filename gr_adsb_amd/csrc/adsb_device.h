@@ -70,11 +70,13 @@ enum RecFlags : unsigned {
   kNoMatch = 4u,   // placeholder whose long pulse did not match the preamble
   kPending = 8u,   // placeholder waiting for k_longrun
   kHead = 16u,     // shard mode: one of the first centres of the shard, delivered whether gated or not
+  kLongHint = 32u, // CANDIDATE words only (long-aware gate, opt-in): the burst's first data bit is set = 112-bit reply
   // Mode S parity pre-filter (decoder.py:550-556 DF, :560-688 check_parity), kDemod only:
   kParityOk = 32u,   // DF 11/17/18/19 (parity/interrogator field) and the 24-bit syndrome is zero
   kLongFmt = 64u,    // DF 16/17/18/19/20/21/24: 112-bit reply (else the decoder reads 56 bits)
   kKnownDf = 128u,   // DF is one the reference decoder checks parity for (0,4,5,11,16-21,24)
   kDfShift = 8u,     // bits 8..12: the downlink format (first five bits, MSB first)
+  kRecLongHint = 0x2000u,   // records of a long-aware context: this burst holds the gate for 119*sps, not 63*sps
 };
 
 // x^j mod G, j = 0..111, G = x^24 + 0xFFF409 (decoder.py:268-269: the 25 coefficients spell 0x1FFF409).  The
@@ -138,6 +140,7 @@ struct DetectArgs {
   float scale;           // MODE 2/3/4: float32 multiplier applied to every integer component
   int sps;
   int end_is_call_end;   // 1: pulse still high at fall_hi is discarded (framer.py:102-108); 0: halo error
+  int long_aware;        // opt-in extension: matched centres carry kLongHint for a length-aware gate
   int rec_cap;           // centres per unit
   int long_cap;
   unsigned long long* cands;  // [units][rec_cap]
@@ -317,7 +320,7 @@ __device__ __forceinline__ BurstFetch<MODE> burst_issue(const DetectArgs& a, uns
   const long long n = a.n, p = uniform64(cand_p(cand));      // the list word is the same in every lane
   const int sps = a.sps, half = sps >> 1;
   f.p = p;
-  f.xflags = cand_flags(cand) & (kKept | kHead);
+  f.xflags = (cand_flags(cand) & (kKept | kHead)) | ((cand_flags(cand) & kLongHint) ? kRecLongHint : 0u);
   const long long w100 = p - kNoise;
   f.fast = w100 >= 0 && w100 >= a.in0_base && p + 136ll * sps < n;
   if (f.fast) {
@@ -711,7 +714,15 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
             }
           }
           if (kAblate == 23) { if (chips == kTemplate) hflag |= 8; }   // (tuning aid: taps read and used, no match kept)
-          else if (chips == kTemplate) res = 0x8000u | (unsigned)p;
+          else if (chips == kTemplate) {
+            res = 0x8000u | (unsigned)p;
+            if (a.long_aware) {                              // first data bit (demod.py:87-95, k = 0): DF >= 16 = long reply
+              const int i1 = p + 16 * half, i0 = i1 + half;
+              const float v1 = (i1 < kWWin) ? s_x[i1] : xg<MODE>(a.data, a.n, t0 + i1, a.scale);
+              const float v0 = (i0 < kWWin) ? s_x[i0] : xg<MODE>(a.data, a.n, t0 + i0, a.scale);
+              if (v1 > v0) res |= 0x10000u;
+            }
+          }
         } else if (!a.end_is_call_end) {
           hflag = 4;
         }
@@ -756,7 +767,7 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
             const int li = atomicAdd(a.long_count, 1);
             if (li < a.long_cap) { LongRise le; le.rise = rg; le.blk = (int)unit; le.slot = slot; a.longlist[li] = le; }
           } else {
-            my_cands[slot] = cand_make(t0 + (long long)(e & 0x7FFFu), 0u);
+            my_cands[slot] = cand_make(t0 + (long long)(e & 0x7FFFu), (e & 0x10000u) ? kLongHint : 0u);
           }
         }
       }
@@ -822,7 +833,12 @@ __global__ void __launch_bounds__(kThreads) k_longrun(DetectArgs a) {
         const float hp = __fmul_rn(xg<MODE>(a.data, a.n, p, a.scale), 0.5f);
         const float v = (lane < 16) ? xg<MODE>(a.data, a.n, p + (long long)lane * (a.sps >> 1), a.scale) : 0.0f;
         const unsigned long long cm = __ballot(lane < 16 && v > hp);
-        if (lane == 0) *out = ((unsigned)cm == kTemplate) ? cand_make(p, 0u) : cand_make(p, kNoMatch);
+        unsigned hint = 0u;
+        if (a.long_aware) {
+          const long long i1 = p + 8ll * a.sps;
+          if (xg<MODE>(a.data, a.n, i1, a.scale) > xg<MODE>(a.data, a.n, i1 + (a.sps >> 1), a.scale)) hint = kLongHint;
+        }
+        if (lane == 0) *out = ((unsigned)cm == kTemplate) ? cand_make(p, hint) : cand_make(p, kNoMatch);
       } else if (lane == 0) {
         *out = cand_make(le.rise, kNoMatch);
         if (!a.end_is_call_end) atomicOr(a.blk_flags + le.blk, 4u);
@@ -924,8 +940,10 @@ __global__ void __launch_bounds__(kThreads) k_gather(const unsigned long long* c
 // 63*sps past its predecessor is accepted whatever happened before it, so it starts an independent
 // chain; each chain head walks its own (short) chain.  Words flagged kNoMatch are skipped.
 __global__ void __launch_bounds__(kThreads) k_resolve(unsigned long long* sorted, const Summary* sum, long long gate,
-                                                      long long prev_eob) {
-  // gate = 63*sps; prev_eob = carried eob as a local index (or very negative)
+                                                      long long gate_long, long long prev_eob) {
+  // gate = 63*sps; gate_long = what a centre flagged kLongHint holds the gate for (119*sps with the long-aware gate,
+  // else == gate: flags are never set then); prev_eob = carried eob as a local index (or very negative).
+  // Chain heads are found with the LARGER window, which is always safe.
   const int n = sum->n_rec;
   const int nseg = (n + kThreads - 1) / kThreads;
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
@@ -934,7 +952,7 @@ __global__ void __launch_bounds__(kThreads) k_resolve(unsigned long long* sorted
       const long long p = cand_p(sorted[i]);
       int j = i - 1;
       while (j >= 0 && (cand_flags(sorted[j]) & kNoMatch)) --j;
-      const bool head = (j < 0) || ((p - cand_p(sorted[j]) > gate) && (p > prev_eob));
+      const bool head = (j < 0) || ((p - cand_p(sorted[j]) > gate_long) && (p > prev_eob));
       if (head) {
         long long eob = (j < 0) ? prev_eob : (p - 1);   // a head with a predecessor is always accepted
         int k = i;
@@ -946,11 +964,11 @@ __global__ void __launch_bounds__(kThreads) k_resolve(unsigned long long* sorted
               // stop at the next head: it owns the rest
               int jj = k - 1;
               while (jj >= 0 && (cand_flags(sorted[jj]) & kNoMatch)) --jj;
-              if (jj >= 0 && pk - cand_p(sorted[jj]) > gate && pk > prev_eob) break;
+              if (jj >= 0 && pk - cand_p(sorted[jj]) > gate_long && pk > prev_eob) break;
             }
             if (pk > eob) {
               sorted[k] = ck | ((unsigned long long)kKept << 56);
-              eob = pk + gate;
+              eob = pk + ((cand_flags(ck) & kLongHint) ? gate_long : gate);
             }
           }
           ++k;

@@ -217,7 +217,7 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   unsigned fmask = 0u, fwant = 0u;
   if (pl.gate) {
     if (tm & 8) hipLaunchKernelGGL(k_resolve, dim3(ag), dim3(kThreads), 0, ts, sorted, (const Summary*)&misc->sum,
-                       (long long)63 * c->sps, pl.prev_eob_stream - pl.origin);
+                       (long long)63 * c->sps, (long long)(pl.long_aware ? 119 : 63) * c->sps, pl.prev_eob_stream - pl.origin);
     fmask = kKept; fwant = kKept;
   }
   if (tm & 16) hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted,
@@ -278,6 +278,7 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   a.data = pl.d_data; a.n = pl.n; a.in0_base = pl.in0_base; a.scan_lo = pl.scan_lo; a.scan_hi = pl.scan_hi;
   a.fall_hi = pl.fall_hi; a.dem_hi = pl.dem_hi; a.origin = pl.origin; a.chunk = chunk; a.thr = c->thr;
   a.prev_in0 = pl.prev_in0; a.scale = c->scale[pl.mode]; a.sps = c->sps; a.end_is_call_end = pl.end_is_call_end; a.rec_cap = s.rec_cap;
+  a.long_aware = pl.long_aware ? 1 : 0;
   a.long_cap = (int)long_cap; a.cands = (unsigned long long*)s.d_cands.p; a.blk_count = (int*)s.d_blk_count.p;
   a.blk_lastp = (long long*)s.d_blk_lastp.p; a.blk_flags = (unsigned*)s.d_blk_flags.p;
   a.longlist = (LongRise*)s.d_long.p; a.long_count = &misc->long_count; a.long_lastp = &misc->long_lastp;
@@ -373,6 +374,7 @@ int canonical(adsb_ctx* c, int mode, const void* d_data, int64_t n, int64_t abs_
   if (!c || n < 0) return -EINVAL;
   if (((uintptr_t)d_data & 15u) != 0) return fail(c, -EINVAL, "device pointer must be 16-byte aligned");
   Plan pl = plan_canonical(mode, d_data, n, abs_offset, c->sps);
+  pl.long_aware = (c->flags & ADSB_FLAG_LONG_AWARE_GATE) != 0;
   Summary s;
   int32_t nres = 0;
   if (n == 0) { c->slot[c->last_slot].nres = 0; if (n_out) *n_out = 0; return 0; }
@@ -598,6 +600,7 @@ static int submit_canonical(adsb_ctx* c, int mode, const void* d_data, int64_t n
   Slot& s = c->slot[c->next_slot];
   if (s.busy) return fail(c, -EBUSY, "every pipeline slot is in flight (adsb_wait first)");
   Plan pl = plan_canonical(mode, d_data, n, abs_offset, c->sps);
+  pl.long_aware = (c->flags & ADSB_FLAG_LONG_AWARE_GATE) != 0;
   int r = enqueue(c, s, pl);
   if (r) { s.busy = false; return r; }
   s.is_shard = false;
@@ -725,6 +728,7 @@ static int shard_plan_checked(adsb_ctx* c, int fmt, const void* d_data, int64_t 
   if (!c || n < 0 || fmt < 0 || fmt >= ADSB_FMT_COUNT || head_cands < 0) return -EINVAL;
   if (((uintptr_t)d_data & 15u) != 0) return fail(c, -EINVAL, "device pointer must be 16-byte aligned");
   *pl = plan_shard(fmt, d_data, n, origin, own_lo, own_hi, stream_len, c->sps, head_cands);
+  pl->long_aware = (c->flags & ADSB_FLAG_LONG_AWARE_GATE) != 0;
   if (origin > 0 && pl->scan_lo < 1) return fail(c, -EINVAL, "shard needs at least one sample of back halo");
   return 0;
 }
@@ -780,16 +784,18 @@ int adsb_shard_fixup(adsb_burst* recs, int32_t n, int sps, int64_t eob_in, int32
   // recs: output of adsb_shard_device(head_cands > 0): every centre of the shard's head (ADSB_BURST_HEAD,
   // complete, gated or not) followed by the centres a fresh-state gate kept.  Re-gate the head with the
   // true incoming eob (framer.py:121-123,165) until the first centre that starts an independent chain
-  // -- more than 63*sps after its predecessor and beyond eob_in: it is accepted whatever came before, so
-  // from there on the fresh-state decisions are exact.
+  // -- beyond the reach (offset + gate window) of every head centre before it and beyond eob_in: it is accepted
+  // whatever came before, so from there on the fresh-state decisions are exact.  The window of a record is
+  // 63*sps (framer.py:165), or 119*sps for records flagged ADSB_BURST_LONG_HINT by a long-aware context.
   if (n < 0 || (n > 0 && !recs) || sps < 2 || !n_kept) return -EINVAL;
-  const long long gate = 63ll * sps;
   int i = 0, w = 0;
-  long long eob = eob_in;
+  long long eob = eob_in, reach = -(1ll << 61);
   bool synced = false;
   for (; i < n && (recs[i].flags & ADSB_BURST_HEAD); ++i) {
     const long long p = recs[i].offset;
-    if (i > 0 && p - recs[i - 1].offset > gate && p > eob_in) { synced = true; break; }
+    const long long gate = ((recs[i].flags & ADSB_BURST_LONG_HINT) ? 119ll : 63ll) * sps;
+    if (i > 0 && p > reach && p > eob_in) { synced = true; break; }
+    if (p + gate > reach) reach = p + gate;
     if (p > eob) {
       eob = p + gate;
       adsb_burst b = recs[i];
@@ -815,7 +821,7 @@ int adsb_stitch(adsb_burst* cands, int32_t n, int sps, int32_t* n_kept) {
   for (int i = 0; i < n; ++i) {
     if (i > 0 && cands[i].offset <= cands[i - 1].offset) return -EINVAL;  // must be in stream order
     if (cands[i].offset > eob) {                                           // framer.py:121
-      eob = cands[i].offset + 63ll * sps;                                  // framer.py:165
+      eob = cands[i].offset + ((cands[i].flags & ADSB_BURST_LONG_HINT) ? 119ll : 63ll) * sps;   // framer.py:165 (+ §8f-4)
       adsb_burst b = cands[i];
       b.flags |= ADSB_BURST_KEPT;
       cands[w++] = b;

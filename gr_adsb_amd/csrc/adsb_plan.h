@@ -22,6 +22,7 @@ struct Plan {
   long long prev_eob_stream;    // framer.py:57 expressed as a stream offset
   bool gate;                // apply framer.py:121-123 on the device
   int head_n = 0;           // shard mode: deliver the first head_n centres whether gated or not
+  bool long_aware = false;  // opt-in length-aware gate (never in GNU Radio emulation): set by the caller from the context
 };
 
 struct FramerState {

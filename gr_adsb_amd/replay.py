@@ -30,10 +30,11 @@ def greedy_gate(cands, sps, eob_in):
     """framer.py:121-123,165 over a block's ungated centres with the incoming end-of-burst state (fallback path)."""
     keep = np.zeros(len(cands), dtype=bool)
     eob = eob_in
+    win = _native.gate_window(cands, sps)
     for i, p in enumerate(cands["offset"]):
         if p > eob:
             keep[i] = True
-            eob = int(p) + 63 * sps
+            eob = int(p) + int(win[i])
     out = cands[keep].copy()
     out["flags"] = (out["flags"] | _native.BURST_KEPT) & ~np.uint16(_native.BURST_HEAD)
     return out
@@ -57,12 +58,12 @@ def replay_blocks(stream_len, sps, block_samples, shard_fn, head_cands=64, head_
         if kept is None:
             kept = greedy_gate(shard_fn(plan, 0), sps, eob)
         if len(kept):
-            eob = int(kept["offset"][-1]) + 63 * sps
+            eob = int(kept["offset"][-1]) + int(_native.gate_window(kept[-1:], sps)[0])
         yield kept
 
 
 class FileReplay:
-    def __init__(self, path, fmt, fs, threshold, block_samples=1 << 26, device=0, scale=None):
+    def __init__(self, path, fmt, fs, threshold, block_samples=1 << 26, device=0, scale=None, long_aware=False):
         self.fmt = FORMATS[fmt] if isinstance(fmt, str) else int(fmt)
         dt, per = _native.FMT_LAYOUT[self.fmt]
         self.items_per_sample = per
@@ -71,7 +72,7 @@ class FileReplay:
         self.fs, self.sps = float(fs), int(fs // 1e6)
         self.block_samples = int(block_samples)
         self.device = device
-        self.ctx = _native.Context(fs, threshold, device=device)
+        self.ctx = _native.Context(fs, threshold, device=device, flags=_native.FLAG_LONG_AWARE_GATE if long_aware else 0)
         if scale is not None:
             self.ctx.set_format_scale(self.fmt, scale)
 
@@ -109,8 +110,10 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--sqlite", default=None, help="record PDUs into this SQLite file (table `demodulated`)")
     ap.add_argument("--parity-only", action="store_true", help="keep only PDUs the decoder's check_parity() can pass")
+    ap.add_argument("--long-aware", action="store_true", help="length-aware re-trigger gate (not the reference's behaviour)")
     args = ap.parse_args(argv)
-    rp = FileReplay(args.path, args.format, args.fs, args.threshold, 1 << args.block_log2, args.device, args.scale)
+    rp = FileReplay(args.path, args.format, args.fs, args.threshold, 1 << args.block_log2, args.device, args.scale,
+                    long_aware=args.long_aware)
     sink = None
     if args.sqlite:
         from .pdu_store import PduSqliteSink

@@ -47,6 +47,13 @@ extern "C" {
 
 /* adsb_create flags */
 #define ADSB_FLAG_TIMING 1u /* bracket the detect kernel with HIP events (adsb_get_stats) */
+/* Opt-in extension, NOT the reference's behaviour: the re-trigger gate holds for the length of the
+ * burst it accepted -- 119*sps when the burst's first data bit is set (DF >= 16: a 112-bit reply), 63*sps otherwise --
+ * instead of always assuming a short reply (framer.py:163-165), so the second half of a long reply can no longer
+ * raise false tags.  Applies to adsb_process_* / adsb_submit_* / adsb_shard_*; adsb_framer_work (the exact GNU Radio
+ * emulation) ignores it.  Records of such a context carry ADSB_BURST_LONG_HINT, which adsb_shard_fixup / adsb_stitch
+ * honour. */
+#define ADSB_FLAG_LONG_AWARE_GATE 2u
 
 /* adsb_burst.flags */
 #define ADSB_BURST_DEMOD 1u /* eob inside the demod input: bits[] valid, a PDU is published (demod.py:82) */
@@ -61,6 +68,7 @@ extern "C" {
 #define ADSB_BURST_KNOWN_DF 128u /* DF is one check_parity() handles: 0,4,5,11,16,17,18,19,20,21,24 */
 #define ADSB_BURST_DF_SHIFT 8    /* (flags >> 8) & 31 = downlink format (decoder.py:551) */
 #define ADSB_BURST_DF(flags) (((flags) >> ADSB_BURST_DF_SHIFT) & 31u)
+#define ADSB_BURST_LONG_HINT 0x2000u /* long-aware contexts only: this burst holds the gate for 119*sps */
 
 typedef struct adsb_ctx adsb_ctx;
 

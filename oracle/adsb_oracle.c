@@ -52,6 +52,12 @@ void oracle_mag2(const float* iq, int64_t n, float* out) {
   }
 }
 
+/* Opt-in, NOT the reference: the length-aware gate of ADSB_FLAG_LONG_AWARE_GATE -- 119*sps after a
+ * burst whose first data bit is set (demod.py:87-95, k = 0; samples past the end read as 0), 63*sps otherwise.  Such
+ * records carry flag 0x2000 like the device's. */
+static int g_long_aware = 0;
+void oracle_set_long_aware(int v) { g_long_aware = v; }
+
 /* x: float32 |IQ|^2 stream of length n.  Returns number of tags written (or -needed if cap too small;
  * the first `cap` are still written).  If cands != NULL every matched centre's stream offset (before the
  * re-trigger gate) is stored there, up to cand_cap, count in *n_cands. */
@@ -85,11 +91,17 @@ int64_t oracle_canonical(const float* x, int64_t n, int sps, float thr, int64_t 
           const int64_t lo = p < 100 ? 0 : p - 100;               /* framer.py:156-159 */
           const float med = median_f32(in0 + lo, (int)(p - lo));
           eob = p + 63 * (int64_t)sps;                            /* framer.py:165 */
+          int lng = 0;
+          if (g_long_aware) {
+            const int64_t i1 = p + 8 * (int64_t)sps, i0 = i1 + half;
+            const float b1 = i1 < n + H - 1 ? in0[i1] : 0.0f, b0 = i0 < n + H - 1 ? in0[i0] : 0.0f;
+            if (b1 > b0) { lng = 1; eob = p + 119 * (int64_t)sps; }
+          }
           const int64_t off = abs_offset - (H - 1) + p;           /* framer.py:170 */
           if (ntags < cap) {
             orec* r = &out[ntags];
             memset(r, 0, sizeof(*r));
-            r->offset = off; r->peak = in0[p]; r->median = med; r->flags = 2;
+            r->offset = off; r->peak = in0[p]; r->median = med; r->flags = (uint16_t)(2 | (lng ? 0x2000 : 0));
             /* demod.py:75-95 on the stream itself (its in0 has no history) */
             const int64_t s_off = off - abs_offset;               /* index into x */
             const double eobd = (double)s_off + 119.0 * sps + sps / 2.0;   /* demod.py:76,80 */

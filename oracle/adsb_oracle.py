@@ -123,9 +123,13 @@ def match_preamble(in0, p, sps):
     return (chips == _TEMPLATE[None, :]).all(axis=1)
 
 
-def framer_call(in0, N, sps, threshold, state, nitems_written):
+def framer_call(in0, N, sps, threshold, state, nitems_written, long_aware=False):
     """One framer.work() call (framer.py:72-182).  in0 has N + 8*sps - 1 items.
-    Returns dict(tag_offsets, peak, median, snr, cand_idx) ; mutates state."""
+    Returns dict(tag_offsets, peak, median, snr, cand_idx) ; mutates state.
+
+    long_aware=True is NOT the reference: it restates the opt-in gate of ADSB_FLAG_LONG_AWARE_GATE,
+    which holds 119*sps after a burst whose first data bit (demod.py:87-95, k = 0; samples past the end read as 0) is
+    set and 63*sps otherwise, instead of framer.py:165's fixed 63*sps.  Only meaningful for one call over a stream."""
     in0 = np.asarray(in0, dtype=np.float32)
     H = NUM_PREAMBLE_BITS * sps
     assert len(in0) == N + H - 1
@@ -145,6 +149,12 @@ def framer_call(in0, N, sps, threshold, state, nitems_written):
                 acc_peak.append(in0[p])
                 acc_med.append(_median_f32(in0[max(0, p - NUM_NOISE_SAMPLES):p]))  # framer.py:156-159
                 eob = p + (NUM_PREAMBLE_BITS + MIN_NUM_BITS - 1) * sps             # framer.py:165
+                if long_aware:
+                    i1, i0 = p + NUM_PREAMBLE_BITS * sps, p + NUM_PREAMBLE_BITS * sps + sps // 2
+                    b1 = in0[i1] if i1 < len(in0) else np.float32(0.0)
+                    b0 = in0[i0] if i0 < len(in0) else np.float32(0.0)
+                    if b1 > b0:
+                        eob = p + (NUM_PREAMBLE_BITS + 112 - 1) * sps
         # framer.py:121-123: the first pulse past eob resets it to -1, matched or not
         if len(centres) and int(centres[-1]) > eob:
             eob = -1
@@ -184,13 +194,14 @@ def demod_call(in0, sps, nitems_read, tag_offsets):
     return sel, bits.reshape(-1, 112), ratio.reshape(-1, 112), conf.reshape(-1, 112)
 
 
-def run_stream(x, fs, threshold, schedule=None, demod_schedule=None):
+def run_stream(x, fs, threshold, schedule=None, demod_schedule=None, long_aware=False):
     """Whole-stream driver mirroring tools/ref_harness.run_reference: x is the float32 |IQ|^2 stream,
     schedule the framer chunk lengths (None = canonical single call), all tags delivered to demod."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     sps = sps_of(fs)
     L = len(x)
     H = NUM_PREAMBLE_BITS * sps
+    assert not (long_aware and schedule is not None), "the long-aware gate is defined for one call over the stream"
     if schedule is None:
         schedule = [L]
     if demod_schedule is None:
@@ -201,7 +212,7 @@ def run_stream(x, fs, threshold, schedule=None, demod_schedule=None):
     offs, peak, med, snr, cands = [], [], [], [], []
     pos = 0
     for N in schedule:
-        r = framer_call(buf[pos:pos + N + H - 1], N, sps, threshold, st, pos)
+        r = framer_call(buf[pos:pos + N + H - 1], N, sps, threshold, st, pos, long_aware=long_aware)
         offs.append(r["tag_offsets"]); peak.append(r["peak"]); med.append(r["median"]); snr.append(r["snr"])
         cands.append(r["cand_idx"] + pos - (H - 1))
         pos += N

@@ -78,3 +78,12 @@ def parity_flags(recs):
             syn[i] = L.oracle_mode_s_parity(bits[i].ctypes.data_as(c.c_void_p), None, None, c.byref(f))
             flags[i] |= f.value
     return flags, syn
+
+
+class long_aware_gate:
+    """with c_oracle.long_aware_gate(): ... -- canonical()/process_iq() restate ADSB_FLAG_LONG_AWARE_GATE (not the reference)."""
+    def __enter__(self):
+        lib().oracle_set_long_aware(1)
+
+    def __exit__(self, *a):
+        lib().oracle_set_long_aware(0)

@@ -19,6 +19,8 @@ struct SimOut {
   long long lastp, last_kept;
 };
 
+static int g_long_aware = 0;      // opt-in length-aware gate (ADSB_FLAG_LONG_AWARE_GATE): set by sim_set_long_aware
+
 #define SIM_BY_MODE(mode, K, ...)                          \
   switch (mode) {                                          \
     case 0: hipsim::launch(K<0>, __VA_ARGS__); break;      \
@@ -68,6 +70,7 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   DetectArgs a;
   a.data = dbuf; a.n = n; a.in0_base = in0_base; a.scan_lo = scan_lo; a.scan_hi = scan_hi; a.fall_hi = fall_hi;
   a.dem_hi = dem_hi; a.origin = origin; a.chunk = chunk; a.thr = thr; a.prev_in0 = prev_in0; a.scale = scale; a.sps = sps;
+  a.long_aware = g_long_aware;
   a.end_is_call_end = end_is_call_end; a.rec_cap = rec_cap; a.long_cap = (int)(ntiles + 1);
   a.cands = cands.data(); a.blk_count = blk_count.data(); a.blk_lastp = blk_lastp.data();
   a.blk_flags = blk_flags.data(); a.longlist = longlist.data(); a.long_count = &long_count;
@@ -84,7 +87,7 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     unsigned fmask = 0u, fwant = 0u;
     if (gate) {
       hipsim::launch(k_resolve, 3, kThreads, sorted.data(), (const Summary*)&sum, (long long)63 * sps,
-                     prev_eob_stream - origin);
+                     (long long)(g_long_aware ? 119 : 63) * sps, prev_eob_stream - origin);
       fmask = kKept; fwant = kKept;
     }
     hipsim::launch(k_count, 3, kThreads, (const unsigned long long*)sorted.data(), (const Summary*)&sum, fmask, fwant,
@@ -102,6 +105,8 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   memcpy(out_recs, src, (size_t)nres * sizeof(Rec));
   return 0;
 }
+
+void sim_set_long_aware(int v) { g_long_aware = v; }
 
 // --- the library's three call shapes, through the same adsb_plan.h the library uses ------------------
 int sim_canonical(int mode, const float* data, long long n, long long abs_offset, float thr, int sps, int grid_max,

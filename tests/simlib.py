@@ -127,3 +127,12 @@ def sim_slice(in0, tag_idx, sps, want_ratio=True):
 
 def unpack_bits(bits14):
     return np.unpackbits(np.asarray(bits14, dtype=np.uint8).reshape(-1, 14), axis=1, bitorder="big")
+
+
+class long_aware_gate:
+    """with simlib.long_aware_gate(): ... -- the emulated device code runs with ADSB_FLAG_LONG_AWARE_GATE semantics."""
+    def __enter__(self):
+        lib().sim_set_long_aware(1)
+
+    def __exit__(self, *a):
+        lib().sim_set_long_aware(0)

@@ -97,6 +97,35 @@ def test_mode_s_syndrome_helper_matches_reference_known_answers(native):
             assert syn == z["aa"][i] and z["parity_passed"][i] == 0
 
 
+def test_stitch_and_fixup_honour_the_long_hint(native):
+    """Host gate functions with records of a long-aware context (ADSB_BURST_LONG_HINT: 119*sps instead of 63*sps);
+    records without the flag behave exactly as before.  Pure host arithmetic."""
+    sps = 2
+    offs = np.array([1000, 1000 + 130, 1000 + 240, 1000 + 400, 5000, 5000 + 127, 5000 + 239], dtype=np.int64)
+    c = np.zeros(len(offs), dtype=native.BURST_DTYPE)
+    c["offset"] = offs
+    c["flags"][[0, 4]] = native.BURST_LONG_HINT          # the bursts at 1000 and 5000 are long replies
+    kept = native.stitch(c, sps)
+    # 1000 (long: gate to 1238) -> 1130 rejected, 1240 accepted (short: to 1366), 1400 accepted; 5000 (long: to 5238) -> 5127 rejected, 5239 accepted
+    assert kept["offset"].tolist() == [1000, 1240, 1400, 5000, 5239]
+    c["flags"] = 0
+    assert native.stitch(c, sps)["offset"].tolist() == [1000, 1130, 1400, 5000, 5127]      # reference gate: 63*sps = 126
+    # fix-up: a head whose first record is long must not sync on a centre inside its window
+    h = np.zeros(5, dtype=native.BURST_DTYPE)
+    h["offset"] = [100, 100 + 200, 100 + 239, 1500, 2000]
+    h["flags"] = native.BURST_HEAD
+    h["flags"][0] |= native.BURST_LONG_HINT | native.BURST_KEPT
+    h["flags"][2] |= native.BURST_KEPT
+    h["flags"][3] |= native.BURST_KEPT                   # beyond everybody's reach: the head syncs here
+    h["flags"][4] = native.BURST_KEPT                    # first record behind the head region
+    out = native.shard_fixup(h, sps, native.EOB_NONE)
+    assert out["offset"].tolist() == [100, 339, 1500, 2000]
+    # with the reference's 63*sps the centre at 300 would already be "more than a window" behind 100: not with the hint
+    assert native.shard_head_sync(h, sps) == 1500 and native.shard_tail(h[:1], sps) == 100 + 119 * sps
+    # (with an incoming eob past 1500 the head cannot sync any more)
+    assert native.shard_fixup(h, sps, 1600) is None
+
+
 def test_stitch_is_the_reference_gate(native):
     from oracle import adsb_oracle as O
     rng = np.random.default_rng(1)

@@ -162,6 +162,55 @@ def test_improved_blocks_are_chunk_invariant(native, name, sched):
     assert np.array_equal(psnr[inside].view(np.uint32), g.get("single", "pdu_snr_bits"))
 
 
+@pytest.mark.parametrize("fs,bps", [(2e6, 3000), (8e6, 6000)])
+def test_long_aware_gate(native, torch_mod, fs, bps):
+    """SURVEY.md §8f-4, opt-in ADSB_FLAG_LONG_AWARE_GATE (not the reference's gate): device == the oracle's restatement
+    of that rule; shards stitch to the single call; the improved blocks with long_aware reproduce it under a chunk
+    schedule; a default context on the same data stays reference-exact."""
+    from gr_adsb_amd import blocks, grshim, replay
+    from gr_adsb_amd import modulator as M
+    from gr_adsb_amd.frontend import shard_plan
+    from oracle import adsb_oracle as O
+    from oracle import c_oracle as C
+    sps, n = int(fs // 1e6), 1 << 21
+    iq = M.synth_iq(n, fs, bps, 55, df_choices=(4, 11, 17, 20), df_weights=(0.2, 0.2, 0.4, 0.2))
+    x = O.mag2(iq)
+    ref = C.canonical(x, sps, np.float32(0.01))
+    with C.long_aware_gate():
+        want = C.canonical(x, sps, np.float32(0.01))
+    assert len(want) < len(ref) and (want["flags"] & native.BURST_LONG_HINT).any()
+    ctx = native.Context(fs, 0.01, flags=native.FLAG_LONG_AWARE_GATE)
+    got = ctx.process_iq(iq)
+    assert_recs_equal(got, want, "long-aware")
+    assert np.array_equal(got["flags"] & native.BURST_LONG_HINT, want["flags"] & native.BURST_LONG_HINT)
+    t = to_dev(torch_mod, iq)
+    assert_recs_equal(ctx.wait(ctx.submit_iq_device(t.data_ptr(), n)), want, "long-aware submitted")
+    lists = [ctx.shard_host(native.FMT_FC32, iq[p["lo"]:p["hi"]], p["lo"], p["own_lo"], p["own_hi"], n) for p in shard_plan(n, 7, sps)]
+    assert_recs_equal(native.stitch(np.concatenate(lists), sps), want, "long-aware stitch")
+    parts = list(replay.replay_blocks(n, sps, 1 << 18, lambda p, hc: ctx.shard_host(native.FMT_FC32, iq[p["lo"]:p["hi"]], p["lo"],
+                                                                                  p["own_lo"], p["own_hi"], n, hc)))
+    assert_recs_equal(np.concatenate(parts), want, "long-aware replay")
+    plain = native.Context(fs, 0.01)
+    r0 = plain.process_iq(iq)
+    assert_recs_equal(r0, ref, "default context") and None
+    assert not (r0["flags"] & native.BURST_LONG_HINT).any()
+    # chunk-invariant blocks with the long-aware gate == the oracle's single call under that rule
+    L = 1 << 18
+    fr = blocks.framer(fs, 0.01, improved=True, long_aware=True)
+    dm = blocks.demod(fs, improved=True)
+    dm.start_timestamp = 0.0
+    pad = fr.delay + 4096
+    xx = np.concatenate([x[:L], np.zeros(pad, np.float32)])
+    sch = [4096] * (L // 4096) + [pad]
+    tags, msgs = grshim.drive(fr, dm, xx, sch)
+    with C.long_aware_gate():
+        w2 = C.canonical(x[:L], sps, np.float32(0.01))
+    # the zero padding completes the bursts the single call drops at the end of its stream: compare the tag set
+    assert np.array_equal(np.array([tg.value[2] for tg in tags], dtype=np.int64), w2["offset"])
+    with pytest.raises(ValueError):
+        blocks.framer(fs, 0.01, long_aware=True)
+
+
 def test_demod_confidence_bits(native):
     g = Golden("g2msps_df17")
     ctx = native.Context(g.fs, g.thr)

@@ -234,3 +234,39 @@ def test_many_units():
     assert so.overflow == 0
     assert_recs_equal(recs, C.canonical(O.mag2(iq), 2, np.float32(0.01)), "160 lists")
     assert len(recs) > 200
+
+
+@pytest.mark.parametrize("fs,bps,mode", [(2e6, 6000, 0), (4e6, 5000, 1), (8e6, 6000, 0), (20e6, 3000, 1)])
+def test_long_aware_gate_matches_its_oracle(fs, bps, mode):
+    """SURVEY.md §8f-4, opt-in (ADSB_FLAG_LONG_AWARE_GATE): the gate holds 119*sps after a burst whose first data bit is
+    set.  Not the reference -- pinned to the oracle's restatement of that rule (NumPy and C agree); the default mode
+    is untouched and never sets the hint flag; overlapped shards still stitch to the single-call result."""
+    sps = int(fs // 1e6)
+    n = 1 << 17
+    iq = M.synth_iq(n, fs, bps, seed=44, df_choices=(4, 11, 17, 20), df_weights=(0.2, 0.2, 0.4, 0.2))
+    x = M.mag2(iq)
+    data = iq if mode == 0 else x
+    ref = C.canonical(x, sps, np.float32(0.01))
+    with C.long_aware_gate():
+        want = C.canonical(x, sps, np.float32(0.01))
+    o = O.run_stream(x, fs, 0.01, long_aware=True)
+    assert np.array_equal(want["offset"], o["tag_offsets"]) and np.array_equal(want["bits"][(want["flags"] & 1) != 0], O.pack_bits(o["pdu_bits"]))
+    assert len(want) <= len(ref) and (sps > 4 or len(want) < len(ref))      # false re-triggers inside long replies are gone
+    with simlib.long_aware_gate():
+        got, _ = simlib.sim_canonical(mode, data, fs, 0.01)
+        assert_recs_equal(got, want, "long-aware canonical")
+        assert np.array_equal(got["flags"] & 0x2000, want["flags"] & 0x2000) and (got["flags"] & 0x2000).any()
+        # overlapped shards, gated per shard + host fix-up, == one call
+        from gr_adsb_amd import _native, replay
+        from gr_adsb_amd.frontend import shard_plan
+
+        def shard_fn(plan, hc):
+            return simlib.sim_shard(mode, data[plan["lo"]:plan["hi"]], plan["lo"], plan["own_lo"], plan["own_hi"], n, fs, 0.01,
+                                    head_cands=hc)[0]
+        parts = list(replay.replay_blocks(n, sps, 1 << 14, shard_fn, head_cands=8))
+        assert_recs_equal(np.concatenate(parts), want, "long-aware replay")
+        ung = np.concatenate([shard_fn(p_, 0) for p_ in shard_plan(n, 5, sps)])
+        assert_recs_equal(_native.stitch(ung, sps), want, "long-aware stitch")
+    got0, _ = simlib.sim_canonical(mode, data, fs, 0.01)
+    assert_recs_equal(got0, ref, "default mode unchanged")
+    assert not (got0["flags"] & 0x2000).any()

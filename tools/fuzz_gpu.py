@@ -22,6 +22,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     _native.load()
     ctxs = {}
+    la_ctxs = {}
     t0 = time.time()
     n_cases = n_bursts = 0
     n_gr = [0]
@@ -73,6 +74,48 @@ def main():
             assert np.array_equal(snr.view(np.uint32), o["tag_snr"].view(np.uint32)), what + " gr snr"
             bits = np.array([m[1] for _, m in msgs], dtype=np.uint8).reshape(-1, 112)
             assert np.array_equal(bits, o["pdu_bits"]), what + " gr pdus"
+            n_gr[0] += 1
+        if rng.random() < 0.3:                        # opt-in length-aware gate vs its oracle restatement
+            la = la_ctxs.setdefault(sps, _native.Context(sps * 1e6, thr, flags=_native.FLAG_LONG_AWARE_GATE))
+            la.set_threshold(thr)
+            with C.long_aware_gate():
+                wl = C.canonical(x, sps, np.float32(thr))
+            assert_recs_equal(la.process_mag2(x), wl, what + " long-aware")
+        if n >= 240 and rng.random() < 0.25:           # integer wire formats: exact conversion, then identical downstream
+            fmt = int(rng.choice([_native.FMT_SC16, _native.FMT_SC8, _native.FMT_CU8]))
+            amp = np.sqrt(np.clip(np.nan_to_num(x, nan=0.0), 0, 1.0)).astype(np.float32)
+            ph = rng.uniform(0, 6.28, n)
+            iqf = (amp * np.exp(1j * ph)).astype(np.complex64)
+            if fmt == _native.FMT_SC16:
+                q, scale = M.quantize_iq16(iqf, full_scale=2.0), float(np.float32(2.0 / 32767.0))
+                xq = O.mag2_iq16(q, scale)
+            else:
+                ob = fmt == _native.FMT_CU8
+                q = M.quantize_iq8(iqf, full_scale=2.0, offset_binary=ob)
+                scale = float(np.float32(2.0 / 255.0 if ob else 2.0 / 127.0))
+                xq = O.mag2_iq8(q, scale, ob)
+            ctx.set_format_scale(fmt, scale)
+            assert_recs_equal(ctx.process_format(fmt, q), C.canonical(xq, sps, np.float32(thr)), what + " fmt %d" % fmt)
+        if rng.random() < 0.1:                         # chunk-invariant blocks on a burst stream, random tiny chunks
+            from gr_adsb_amd import blocks, grshim
+            L = int(rng.choice([3000, 9000, 20000]))
+            iqb = M.synth_iq(L, sps * 1e6, float(rng.choice([3000, 20000, 60000])), int(rng.integers(1 << 30)))
+            xb = O.mag2(iqb)
+            fr, dm = blocks.framer(sps * 1e6, 0.01, improved=True), blocks.demod(sps * 1e6, improved=True)
+            dm.start_timestamp = 0.0
+            pad = fr.delay + 512
+            xx = np.concatenate([xb, np.zeros(pad, np.float32)])
+            sch = []
+            while sum(sch) < len(xx):
+                sch.append(int(min(rng.choice([1, 3, 50, 257, 1024, 5000]), len(xx) - sum(sch))))
+            tags, msgs = grshim.drive(fr, dm, xx, sch)
+            wb = C.canonical(xb, sps, np.float32(0.01))
+            assert np.array_equal(np.array([t.value[2] for t in tags], dtype=np.int64), wb["offset"]), what + " improved tags"
+            offs = np.array([int(round(m[0]["timestamp"] * sps * 1e6)) for _, m in msgs], dtype=np.int64)
+            bits = np.array([m[1] for _, m in msgs], dtype=np.uint8).reshape(-1, 112)
+            dem = (wb["flags"] & 1) != 0
+            inside = offs + 119 * sps + sps // 2 < L
+            assert np.array_equal(offs[inside], wb["offset"][dem]) and np.array_equal(np.packbits(bits[inside], axis=1), wb["bits"][dem]), what + " improved pdus"
             n_gr[0] += 1
         n_cases += 1
         n_bursts += len(want)

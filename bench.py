@@ -148,7 +148,7 @@ def main():
         iq = gen_stream_blocks(plan["hi"] - plan["lo"], plan["lo"], fs, args.bursts, args.seed, dev)
     torch.cuda.synchronize()
 
-    DEPTH = _native.MAX_IN_FLIGHT
+    DEPTH = int(os.environ.get("ADSB_BENCH_DEPTH", _native.MAX_IN_FLIGHT))     # (tuning aid: needs a library built with that many slots)
     pending = []          # tickets of submitted, not yet collected passes (pipeline of DEPTH passes)
 
     def step():

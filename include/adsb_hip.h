@@ -32,7 +32,9 @@ extern "C" {
 #endif
 
 #define ADSB_ABI_VERSION 1
+#ifndef ADSB_MAX_IN_FLIGHT
 #define ADSB_MAX_IN_FLIGHT 3 /* adsb_submit_* calls that may be pending at once */
+#endif
 
 /* Input sample formats (the `format` / `fmt` argument).  The reference's flowgraph feeds complex64 from the
  * SDR source through complex_to_mag_squared (examples/adsb_rx.py:116,180); the integer formats are the same

@@ -159,7 +159,8 @@ int detect_occupancy() {
 template <int MODE>
 void launch_burst(adsb_ctx* c, hipStream_t st, const DetectArgs& a, const unsigned long long* kept, const Summary* sum,
                   Rec* out, int cap, Summary* host_sum) {
-  hipLaunchKernelGGL((k_burst<MODE>), dim3(c->n_cu * 8), dim3(kThreads), 0, st, a, kept, sum, out, cap, host_sum);
+  static const int bg = getenv("ADSB_DEBUG_BURST_GRID") ? atoi(getenv("ADSB_DEBUG_BURST_GRID")) : 8;   // tuning probe: workgroups per CU
+  hipLaunchKernelGGL((k_burst<MODE>), dim3(c->n_cu * bg), dim3(kThreads), 0, st, a, kept, sum, out, cap, host_sum);
 }
 template <int MODE>
 void launch_longrun(hipStream_t st, const DetectArgs& a) {

@@ -371,18 +371,26 @@ def gate_window(recs, sps):
 
 
 def shard_head_sync(recs, sps):
-    """What decides -- for ANY incoming eob -- whether shard_fixup can succeed on this shard: the largest offset
-    of a head-region centre that lies more than 63*sps after its predecessor (fixup succeeds iff that offset is
-    beyond the incoming eob), SYNC_ALWAYS when the whole shard fits in the head region, EOB_NONE if there is no
-    such centre."""
-    fl = recs["flags"]
-    nh = int(np.count_nonzero(fl[:MAX_HEAD] & BURST_HEAD)) if len(recs) else 0
-    if nh == len(recs):
+    """The one number that tells every rank -- for ANY incoming eob -- whether this shard's fresh-state gate
+    decisions (and therefore its fresh-state tail, shard_tail) are exact from some head centre on: the largest
+    offset of a head-region centre that starts an independent chain, i.e. lies beyond the reach (offset + gate
+    window) of every head centre before it (the first centre of a shard always does).  If that offset is beyond
+    the incoming eob the centre is accepted by the true gate and by the fresh-state gate alike, both hold the
+    same state from there on, adsb_shard_fixup succeeds and the tail published from the fresh-state gate is the
+    true one.  SYNC_ALWAYS for a shard without any centre (its tail is EOB_NONE: the incoming state passes
+    through).  A shard that lies ENTIRELY in its head region gets no special treatment: its own fix-up could not
+    fail, but if all its chain heads are at or before the incoming eob its true tail depends on that eob and the
+    fresh-state tail it published would be stale (round-1 bug: such shards returned SYNC_ALWAYS)."""
+    if len(recs) == 0:
         return SYNC_ALWAYS
+    fl = recs["flags"]
+    nh = int(np.count_nonzero(fl[:MAX_HEAD] & BURST_HEAD))
+    if nh == 0:
+        return EOB_NONE
     off = recs["offset"][:nh]
     reach = np.maximum.accumulate(off + gate_window(recs[:nh], sps))      # how far the centres so far can hold the gate
     idx = np.flatnonzero(off[1:] > reach[:-1])
-    return int(off[idx[-1] + 1]) if len(idx) else EOB_NONE
+    return int(off[idx[-1] + 1]) if len(idx) else int(off[0])
 
 
 def shard_tail(recs, sps):

@@ -785,9 +785,12 @@ int adsb_shard_fixup(adsb_burst* recs, int32_t n, int sps, int64_t eob_in, int32
   // recs: output of adsb_shard_device(head_cands > 0): every centre of the shard's head (ADSB_BURST_HEAD,
   // complete, gated or not) followed by the centres a fresh-state gate kept.  Re-gate the head with the
   // true incoming eob (framer.py:121-123,165) until the first centre that starts an independent chain
-  // -- beyond the reach (offset + gate window) of every head centre before it and beyond eob_in: it is accepted
-  // whatever came before, so from there on the fresh-state decisions are exact.  The window of a record is
-  // 63*sps (framer.py:165), or 119*sps for records flagged ADSB_BURST_LONG_HINT by a long-aware context.
+  // -- beyond the reach (offset + gate window) of every head centre before it (trivially true for the first one)
+  // and beyond eob_in: it is accepted whatever came before, so from there on the fresh-state decisions are exact.
+  // A shard that lies entirely in its head region is re-gated completely and never fails; whether its END-OF-BURST
+  // state equals the fresh-state one is a separate question the caller answers with the same criterion
+  // (gr_adsb_amd/_native.py shard_head_sync; sharding.finish_shard falls back to adsb_stitch when it does not).
+  // The window of a record is 63*sps (framer.py:165), or 119*sps for records flagged ADSB_BURST_LONG_HINT by a long-aware context.
   if (n < 0 || (n > 0 && !recs) || sps < 2 || !n_kept) return -EINVAL;
   int i = 0, w = 0;
   long long eob = eob_in, reach = -(1ll << 61);
@@ -795,7 +798,7 @@ int adsb_shard_fixup(adsb_burst* recs, int32_t n, int sps, int64_t eob_in, int32
   for (; i < n && (recs[i].flags & ADSB_BURST_HEAD); ++i) {
     const long long p = recs[i].offset;
     const long long gate = ((recs[i].flags & ADSB_BURST_LONG_HINT) ? 119ll : 63ll) * sps;
-    if (i > 0 && p > reach && p > eob_in) { synced = true; break; }
+    if (p > reach && p > eob_in) { synced = true; break; }   // also i == 0: the first centre lies beyond eob_in
     if (p + gate > reach) reach = p + gate;
     if (p > eob) {
       eob = p + gate;

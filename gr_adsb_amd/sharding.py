@@ -121,9 +121,16 @@ def finish_shard(recs, sps, rank, all_gather_pair, ungated_fn, all_gather_obj, i
     ONE collective of the common path; ungated_fn() -> this shard's ungated candidates (fallback only);
     all_gather_obj(o) -> list of every rank's object (fallback only).  Returns this rank's exact kept bursts.
 
-    Every rank publishes its end-of-burst tail and its head-sync offset; from those every rank can tell, for
-    every rank, whether the local fix-up will succeed, so all ranks agree on the (rare) fallback without a
-    second collective."""
+    Every rank publishes its fresh-state end-of-burst tail and its head-sync offset (shard_head_sync: the last
+    head centre that starts an independent chain).  By induction over the ranks: shard 0's incoming state is
+    "none"; if shard r's sync offset lies beyond its true incoming eob, the true gate and the fresh-state gate
+    agree from that centre on, so the local fix-up succeeds AND the published fresh-state tail is shard r's true
+    tail -- which makes the incoming eob computed for shard r+1 the true one.  If the condition fails for any
+    shard (its head region ends inside an unbroken chain, or a short shard -- at most HEAD_CANDS centres, all in
+    one chain reached by the incoming eob -- whose true tail therefore depends on that eob), every rank sees
+    the same failure from the same gathered pairs and all take the full-candidate fallback together, without a
+    second collective.  The result equals adsb_stitch over the whole stream in every case
+    (tests/test_shard_stitch_property.py)."""
     pairs = all_gather_pair((_native.shard_tail(recs, sps), _native.shard_head_sync(recs, sps)))
     tails = [t for t, _ in pairs]
     ok = all(sync > incoming_eob(tails, r) for r, (_, sync) in enumerate(pairs))

@@ -143,7 +143,7 @@ def test_stitch_is_the_reference_gate(native):
 
 
 def test_head_sync_predicts_fixup_and_fixup_is_exact(native):
-    """Host-only: for random centre lists, (1) shard_head_sync() > eob_in  <=>  adsb_shard_fixup succeeds,
+    """Host-only: for random centre lists, (1) shard_head_sync() > eob_in  <=>  adsb_shard_fixup succeeds (=> only, for a shard that is all head),
     (2) when it succeeds the result equals the sequential gate started from eob_in."""
     from oracle import adsb_oracle as O
     rng = np.random.default_rng(7)
@@ -163,7 +163,10 @@ def test_head_sync_predicts_fixup_and_fixup_is_exact(native):
         want = off[O.resolve_candidates(off, sps, prev_eob=eob_in)]
         got = native.shard_fixup(recs, sps, eob_in)
         predicted = native.shard_head_sync(recs, sps) > eob_in
-        assert predicted == (got is not None)
+        all_head = head_n >= n
+        # the prediction is exact unless the whole shard lies in its head region: such a shard's fix-up cannot
+        # fail, but the prediction must still say "no" when its tail depends on eob_in (test_shard_stitch_property.py)
+        assert predicted == (got is not None) or (all_head and got is not None and not predicted)
         if got is not None:
             assert np.array_equal(got["offset"], want)
             assert np.all(got["flags"] & 2) and not np.any(got["flags"] & 16)

@@ -16,6 +16,9 @@ assert BURST_DTYPE.itemsize == 32
 
 FLAG_TIMING = 1
 FLAG_LONG_AWARE_GATE = 2  # opt-in: the gate holds 119*sps after a burst whose first data bit is set
+FLAG_CONFIDENCE = 4       # opt-in: keep demod.bit_confidence's ratios (demod.py:97-101) for the whole-buffer entry points
+FLAG_SINGLE_STREAM = 8    # profiling aid: the sparse tail of a pass on the compute stream instead of beside the next pass
+ABI_VERSION = 2
 # input sample formats (include/adsb_hip.h ADSB_FMT_*): numpy dtype of the flat host array, items per sample
 FMT_FC32, FMT_MAG2, FMT_SC16, FMT_SC8, FMT_CU8 = 0, 1, 2, 3, 4
 FMT_LAYOUT = {FMT_FC32: (np.complex64, 1), FMT_MAG2: (np.float32, 1), FMT_SC16: (np.int16, 2), FMT_SC8: (np.int8, 2),
@@ -36,6 +39,7 @@ EXPORTS = [
     "adsb_submit_iq_device", "adsb_submit_mag2_device", "adsb_submit_iq16_device", "adsb_submit_shard_device", "adsb_wait",
     "adsb_set_iq16_scale", "adsb_process_iq16", "adsb_process_iq16_device",
     "adsb_set_format_scale", "adsb_process_format", "adsb_process_format_device", "adsb_submit_format_device",
+    "adsb_submit_format_host", "adsb_last_confidence",
     "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_shard_host", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_mode_s_syndrome", "adsb_get_stats",
     "adsb_reset_stats", "adsb_last_error", "adsb_host_alloc", "adsb_host_free",
 ]
@@ -94,6 +98,8 @@ def load():
     lib.adsb_process_format.argtypes = [vp, c.c_int, vp, i64, i64, vp, i32, c.POINTER(i32)]
     lib.adsb_process_format_device.argtypes = [vp, c.c_int, vp, i64, i64, vp, i32, c.POINTER(i32)]
     lib.adsb_submit_format_device.argtypes = [vp, c.c_int, vp, i64, i64, c.POINTER(i32)]
+    lib.adsb_submit_format_host.argtypes = [vp, c.c_int, vp, i64, i64, c.POINTER(i32)]
+    lib.adsb_last_confidence.argtypes = [vp, c.POINTER(vp), c.POINTER(i32)]
     lib.adsb_last_result.argtypes = [vp, c.POINTER(vp), c.POINTER(i32)]
     lib.adsb_submit_iq_device.argtypes = [vp, vp, i64, i64, c.POINTER(i32)]
     lib.adsb_submit_mag2_device.argtypes = [vp, vp, i64, i64, c.POINTER(i32)]
@@ -172,6 +178,30 @@ class Context:
         buf = (ctypes.c_char * (n.value * 32)).from_address(p.value)
         v = np.frombuffer(buf, dtype=BURST_DTYPE)
         return v.copy() if copy else v
+
+    def last_confidence(self, copy=True):
+        """FLAG_CONFIDENCE contexts: float32 [n,112] ratios bit1_amp / bit0_amp of the last finished call's bursts
+        (demod.py:91-101); confidence_db() turns them into demod.bit_confidence."""
+        p = ctypes.c_void_p()
+        n = ctypes.c_int32(0)
+        self._chk(self.lib.adsb_last_confidence(self._h, ctypes.byref(p), ctypes.byref(n)))
+        if n.value == 0:
+            return np.zeros((0, 112), dtype=np.float32)
+        buf = (ctypes.c_char * (n.value * 112 * 4)).from_address(p.value)
+        v = np.frombuffer(buf, dtype=np.float32).reshape(n.value, 112)
+        return v.copy() if copy else v
+
+    def submit_format_host(self, fmt, data, abs_offset=0):
+        """Host-fed pipelined submission (adsb_submit_format_host): data = host array in the format's layout; a
+        page-locked one (PinnedArray, torch pin_memory) is DMA'd where it lies and must stay alive until wait()."""
+        dt, per = FMT_LAYOUT[int(fmt)]
+        data = np.ascontiguousarray(data, dtype=dt)
+        t = ctypes.c_int32(-1)
+        self._chk(self.lib.adsb_submit_format_host(self._h, int(fmt), ctypes.c_void_p(data.ctypes.data), len(data) // per,
+                                                   int(abs_offset), ctypes.byref(t)))
+        self._host_keepalive = getattr(self, "_host_keepalive", {})
+        self._host_keepalive[t.value] = data
+        return t.value
 
     def process_iq(self, iq, abs_offset=0):
         iq = np.ascontiguousarray(iq, dtype=np.complex64)
@@ -429,6 +459,12 @@ def mode_s_syndrome(bits14):
 def unpack_bits(bits14):
     """[n,14] packed bytes -> [n,112] 0/1 uint8 (the u8vector layout of the reference PDU)."""
     return np.unpackbits(np.asarray(bits14, dtype=np.uint8).reshape(-1, 14), axis=1, bitorder="big")
+
+
+def confidence_db(ratio):
+    """demod.py:101: bit_confidence = 10*log10(bit1_amp / bit0_amp), float32 with NumPy itself (like snr_db)."""
+    with np.errstate(all="ignore"):
+        return (np.float32(10.0) * np.log10(np.asarray(ratio, dtype=np.float32))).astype(np.float32)
 
 
 def snr_db(peak, median):

@@ -1,12 +1,15 @@
 // adsb_device.h -- CDNA4 (gfx950) device code for the ADS-B front end.
 //
 //   k_detect   streams the IQ once: |IQ|^2 -> threshold bitmask (one __ballot per 64 samples) -> rises by
-//              mask algebra -> pulse centre -> 16-chip preamble test; emits matched centres per wavefront
+//              mask algebra -> pulse centre -> 16-chip preamble test -> for every match, while its samples are
+//              still in the wavefront's LDS window, the complete burst record (peak, median-of-100 noise,
+//              112-bit PPM slice, Mode S parity pre-filter): the stream is never read a second time
 //   k_longrun  (rare) pulses longer than the LDS window
-//   k_scan / k_gather / k_resolve / k_count / k_compact
-//              order the centres, apply the re-trigger gate as parallel chain walks, compact
-//   k_burst    one wavefront per surviving centre: peak, median-of-100 noise, 112-bit PPM slice
-//   k_slice    PPM slice for a caller-supplied tag list (the stand-alone demod block)
+//   k_scan / k_gather / k_resolve / k_count / k_compact / k_publish
+//              order the centres and their records, apply the re-trigger gate as parallel chain walks, compact
+//              the survivors' records, hand the summary to the host
+//   k_slice    PPM slice (+ confidence ratio) for a tag list: the stand-alone demod block, and the opt-in
+//              confidence output of the fused path
 //
 // Written for 64-wide wavefronts: the threshold mask of 64 samples IS a ballot, rises/falls are 64-bit
 // mask algebra, compaction is ballot + prefix-popcount, per-burst work is done by a whole wavefront.
@@ -20,7 +23,8 @@
 // This header contains device code only and includes nothing.  The includer provides the HIP device
 // environment plus `adsb_wave_sync()` (a wavefront-level execution/LDS ordering point), `adsb_uniform(int)`
 // (marks a wavefront-uniform value so it lives in a scalar register), `adsb_readlane(int, lane)` and
-// `adsb_bitrep32(u32) -> u64` (every bit doubled: s_bitreplicate_b64_b32): the
+// `adsb_bitrep32(u32) -> u64` (every bit doubled: s_bitreplicate_b64_b32), `adsb_opaque(int)` (returns its argument
+// through an empty asm statement, so that nothing derived from it is treated as loop invariant): the
 // product translation unit adsb_hip.hip maps them to __builtin_amdgcn_wave_barrier() / _readfirstlane() /
 // _readlane(); tests/sim/sim_driver.cpp includes the test-only SIMT emulator instead, so the very same
 // kernels run on a machine without a GPU.
@@ -32,6 +36,7 @@ constexpr int kThreads = 256;            // 4 wavefronts per workgroup
 constexpr int kWaves = kThreads / 64;
 constexpr int kWTile = 1024;             // samples a wavefront owns per tile iteration (16 ballot words)
 constexpr int kFwd = 256;                // forward halo kept in LDS behind every tile
+constexpr int kBack = 128;               // back halo kept in LDS in front of every tile: the <=100-sample noise window (framer.py:156)
 constexpr int kWWin = kWTile + kFwd;
 constexpr int kWWords = kWWin / 64;      // 20
 constexpr int kWOwn = kWTile / 64;       // 16: word owners are lanes 0..15
@@ -40,17 +45,8 @@ constexpr unsigned kTemplate = 0x285u;   // chips 0,2,7,9 high (framer.py:50)
 constexpr int kNoise = 100;              // framer.py:31
 constexpr long long kNoIndex = -(1ll << 62);
 static_assert(kWOwn == 16 && kFwd % 64 == 0, "word owners are lanes 0..15 of each wavefront");
+static_assert(kBack % 64 == 0 && kBack >= 100, "the noise window of a centre in the tile must lie in the LDS window");
 
-// Tuning aid (tools/kbench.py builds side copies of the library with -DADSB_ABLATE=k to time phases of
-// k_detect in isolation); the shipped library is always built with 0 = nothing skipped.
-//   4 loads only | 3 + LDS commit | 2 + threshold masks, rise/fall flags | 21 + rise lists | 22 + falls, centres
-//   23 + the 16 taps (matches discarded) | 0 everything.  Measured round 1 (2 Msps / 8 Msps dense, ms):
-//   0.347 | 0.355 | 0.365/0.363 | 0.380/0.410 | 0.393/0.424 | 0.407/0.441 | 0.41-0.42/0.43-0.44
-#ifndef ADSB_ABLATE
-#define ADSB_ABLATE 0
-#endif
-constexpr int kAblate = ADSB_ABLATE;
-constexpr bool kNoMasks = kAblate >= 3 && kAblate < 20;   // 3, 4: streaming only; 21..24 probe the rise path
 // k_detect is latency bound per workgroup: 5 resident workgroups per CU (<= 96 VGPRs, no spills) measured
 // 15-20 % faster than 4; 6 would need spills to scratch.
 // Number of prefetch registers (of Span::ITER) reloaded inside the commit loop, right after their samples were
@@ -100,7 +96,8 @@ constexpr unsigned kDfPiSet = (1u << 11) | (1u << 17) | (1u << 18) | (1u << 19);
 
 // 32-byte burst record: w0 = stream offset (int64); w1 = peak | median<<32 (float bits);
 // w2 = bits 0..63 as bytes 0..7 (first bit = MSB of byte 0); w3 = bytes 8..13 | flags<<48.
-struct Rec { unsigned long long w[4]; };
+struct alignas(16) Rec { unsigned long long w[4]; };
+struct alignas(16) RecHalf { unsigned long long a, b; };
 
 // A matched centre travels between kernels as one 64-bit word: flags<<56 | (local index + kBias).
 constexpr long long kBias = 1ll << 40;
@@ -144,6 +141,7 @@ struct DetectArgs {
   int rec_cap;           // centres per unit
   int long_cap;
   unsigned long long* cands;  // [units][rec_cap]
+  Rec* recs;             // [units][rec_cap]: the burst record of every matched centre, same slot as its list word
   int* blk_count;        // [units]
   long long* blk_lastp;  // [units]
   unsigned* blk_flags;   // [units]
@@ -179,7 +177,7 @@ constexpr bool mode_is_iq8(int mode) { return mode == 3 || mode == 4; }
 constexpr int mode_bytes(int mode) { return mode == 0 ? 8 : mode_is_iq8(mode) ? 2 : 4; }   // bytes per sample
 
 // One sample as it lies in memory (RawSel<MODE>::type) and its conversion to |IQ|^2, kept apart so that a
-// gather can be issued long before its value is needed (k_burst fetches the next burst while it works on this one).
+// gather can be issued long before its value is needed.
 template <int MODE> struct RawSel { using type = float; };
 template <> struct RawSel<0> { using type = float2; };
 template <> struct RawSel<2> { using type = unsigned; };
@@ -320,7 +318,7 @@ __device__ __forceinline__ BurstFetch<MODE> burst_issue(const DetectArgs& a, uns
   const long long n = a.n, p = uniform64(cand_p(cand));      // the list word is the same in every lane
   const int sps = a.sps, half = sps >> 1;
   f.p = p;
-  f.xflags = (cand_flags(cand) & (kKept | kHead)) | ((cand_flags(cand) & kLongHint) ? kRecLongHint : 0u);
+  f.xflags = (cand_flags(cand) & kLongHint) ? kRecLongHint : 0u;      // the tail adds kKept / kHead (k_compact)
   const long long w100 = p - kNoise;
   f.fast = w100 >= 0 && w100 >= a.in0_base && p + 136ll * sps < n;
   if (f.fast) {
@@ -349,41 +347,14 @@ __device__ __forceinline__ BurstFetch<MODE> burst_issue(const DetectArgs& a, uns
   return f;
 }
 
-template <int MODE>
-__device__ void burst_finish(const DetectArgs& a, const BurstFetch<MODE>& f, Rec* out, int lane, const ParityConsts& pc) {
-  const long long n = a.n, p = f.p;
-  const unsigned xflags = f.xflags;
-  const int sps = a.sps, half = sps >> 1;
-  const bool dem = p + 119ll * sps + half < a.dem_hi;   // demod.py:76,82 (sps even)
-  const bool dem1 = dem && lane < 48;
-  int nwin;
-  float peak, v0, v1, x1, x0, y1, y0;
-  bool val0, val1;
-  if (f.fast) {                                          // wave-uniform
-    nwin = kNoise; val0 = true; val1 = lane < kNoise - 64;
-    peak = raw_mag2<MODE>(f.peak, a.scale);
-    v0 = raw_mag2<MODE>(f.w0, a.scale);
-    v1 = val1 ? raw_mag2<MODE>(f.w1, a.scale) : 0.0f;
-    x1 = raw_mag2<MODE>(f.x1, a.scale); x0 = raw_mag2<MODE>(f.x0, a.scale);
-    y1 = raw_mag2<MODE>(f.y1, a.scale); y0 = raw_mag2<MODE>(f.y0, a.scale);
-  } else {
-    long long wlo = p - kNoise;
-    if (wlo < a.in0_base) wlo = a.in0_base;
-    nwin = (int)(p - wlo);
-    val0 = lane < nwin; val1 = lane + 64 < nwin;
-    const long long s0 = p + 8ll * sps + (long long)lane * sps;
-    const long long s1 = s0 + 64ll * sps;
-    auto val = [&](typename RawSel<MODE>::type r, long long i) -> float {     // x(i) = 0 outside the buffer
-      const float v = raw_mag2<MODE>(r, a.scale);
-      return ((i >= 0) & (i < n)) ? v : 0.0f;
-    };
-    peak = val(f.peak, p);
-    v0 = val0 ? val(f.w0, wlo + lane) : 0.0f;
-    v1 = val1 ? val(f.w1, wlo + lane + 64) : 0.0f;
-    x1 = val(f.x1, s0); x0 = val(f.x0, s0 + half);
-    y1 = val(f.y1, s1); y0 = val(f.y0, s1 + half);
-  }
-
+// The part of a burst record every path shares, once the wavefront holds the burst's samples: lane l has window
+// samples l and l+64 (v0, v1; valid iff val0, val1; nwin = window length, framer.py:156), bit-pair l (x1, x0) and,
+// for l < 48, bit-pair 64+l (y1, y0) (demod.py:87-92); peak = in0[pulse_idx].  `dem` = the burst ends inside the demod
+// input (demod.py:82).  xflags: record flags already known (kRecLongHint; the tail adds kKept / kHead).  Lane 0
+// stores the 32-byte record.
+__device__ __forceinline__ void burst_reduce(long long offset, int nwin, bool val0, bool val1, float peak, float v0,
+                                             float v1, bool dem, float x1, float x0, float y1, float y0, unsigned xflags,
+                                             Rec* out, int lane, const ParityConsts& pc) {
   const unsigned long long nanm = __ballot((val0 && v0 != v0) || (val1 && v1 != v1));
   const unsigned k0 = val0 ? f32_key(v0) : 0xFFFFFFFFu;      // lanes outside the window sort last
   const unsigned k1 = val1 ? f32_key(v1) : 0xFFFFFFFFu;
@@ -415,7 +386,7 @@ __device__ void burst_finish(const DetectArgs& a, const BurstFetch<MODE>& f, Rec
     const unsigned B = (cle >= ((nwin - 1) >> 1) + 2) ? A : m;
     med = __fmul_rn(__fadd_rn(key_f32(A), key_f32(B)), 0.5f);          // f32(a+b)/2
   }
-  const bool bitA = dem && x1 > x0, bitB = dem1 && y1 > y0;                                // demod.py:95
+  const bool bitA = dem && x1 > x0, bitB = dem && lane < 48 && y1 > y0;                     // demod.py:95
   const unsigned long long ma = __ballot(bitA), mb = __ballot(bitB);
   const unsigned pflags = parity_prefilter(ma, mb, pc);
   if (lane == 0) {
@@ -423,13 +394,85 @@ __device__ void burst_finish(const DetectArgs& a, const BurstFetch<MODE>& f, Rec
     const unsigned long long rb = __builtin_bswap64(__brevll(mb)) & 0xFFFFFFFFFFFFull;
     const unsigned flags = (dem ? (kDemod | pflags) : 0u) | xflags;
     Rec r;
-    r.w[0] = (unsigned long long)(a.origin + p);
+    r.w[0] = (unsigned long long)offset;
     r.w[1] = (unsigned long long)__builtin_bit_cast(unsigned, peak) |
              ((unsigned long long)__builtin_bit_cast(unsigned, med) << 32);
     r.w[2] = ra;
     r.w[3] = rb | ((unsigned long long)flags << 48);
     *out = r;
   }
+}
+
+// Record of a centre whose samples come from global memory (k_longrun: pulses longer than the LDS window).
+template <int MODE>
+__device__ void burst_finish(const DetectArgs& a, const BurstFetch<MODE>& f, Rec* out, int lane, const ParityConsts& pc) {
+  const long long n = a.n, p = f.p;
+  const int sps = a.sps, half = sps >> 1;
+  const bool dem = p + 119ll * sps + half < a.dem_hi;   // demod.py:76,82 (sps even)
+  int nwin;
+  float peak, v0, v1, x1, x0, y1, y0;
+  bool val0, val1;
+  if (f.fast) {                                          // wave-uniform
+    nwin = kNoise; val0 = true; val1 = lane < kNoise - 64;
+    peak = raw_mag2<MODE>(f.peak, a.scale);
+    v0 = raw_mag2<MODE>(f.w0, a.scale);
+    v1 = val1 ? raw_mag2<MODE>(f.w1, a.scale) : 0.0f;
+    x1 = raw_mag2<MODE>(f.x1, a.scale); x0 = raw_mag2<MODE>(f.x0, a.scale);
+    y1 = raw_mag2<MODE>(f.y1, a.scale); y0 = raw_mag2<MODE>(f.y0, a.scale);
+  } else {
+    long long wlo = p - kNoise;
+    if (wlo < a.in0_base) wlo = a.in0_base;
+    nwin = (int)(p - wlo);
+    val0 = lane < nwin; val1 = lane + 64 < nwin;
+    const long long s0 = p + 8ll * sps + (long long)lane * sps;
+    const long long s1 = s0 + 64ll * sps;
+    auto val = [&](typename RawSel<MODE>::type r, long long i) -> float {     // x(i) = 0 outside the buffer
+      const float v = raw_mag2<MODE>(r, a.scale);
+      return ((i >= 0) & (i < n)) ? v : 0.0f;
+    };
+    peak = val(f.peak, p);
+    v0 = val0 ? val(f.w0, wlo + lane) : 0.0f;
+    v1 = val1 ? val(f.w1, wlo + lane + 64) : 0.0f;
+    x1 = val(f.x1, s0); x0 = val(f.x0, s0 + half);
+    y1 = val(f.y1, s1); y0 = val(f.y0, s1 + half);
+  }
+  burst_reduce(a.origin + p, nwin, val0, val1, peak, v0, v1, dem, x1, x0, y1, y0, f.xflags, out, lane, pc);
+}
+
+// Record of a centre found by k_detect, built by the whole wavefront while the centre's tile is still in its LDS
+// window s_x[-kBack .. kWWin) (index j <-> sample t0 + j; samples outside the buffer are zeros there too): the noise
+// window always lies inside it, the bit samples do for all of a 2 Msps burst that starts in the tile and for the
+// beginning of longer ones -- samples past the window come from global memory (they are the next thing this
+// wavefront streams anyway, so that fetch is served by the caches a moment later).  p = centre relative to t0.
+// Deliberately NOT inlined, with every input passed by value: the streaming loop of k_detect keeps its register
+// allocation (a by-reference DetectArgs would force the kernel arguments into scratch memory), and the cost of a
+// real call is paid once per matched preamble.
+struct WinArgs {
+  const void* data; long long n, in0_base, dem_hi, origin; float scale; int sps;
+};
+template <int MODE>
+__device__ __attribute__((noinline)) void burst_from_window(WinArgs a, const float* s_x, long long t0, int p,
+                                                            unsigned xflags, Rec* out, int lane) {
+  const int sps = a.sps, half = sps >> 1;
+  const long long P = t0 + p;
+  long long wlo = P - kNoise;                                // framer.py:156: in0[max(0, pulse_idx-100) : pulse_idx]
+  if (wlo < a.in0_base) wlo = a.in0_base;
+  const int nwin = (int)(P - wlo);
+  const int wl = (int)(wlo - t0);                            // >= p - 100 >= -kBack
+  const bool val0 = lane < nwin, val1 = lane + 64 < nwin;
+  const float v0 = val0 ? s_x[wl + lane] : 0.0f;
+  const float v1 = val1 ? s_x[wl + lane + 64] : 0.0f;
+  const float peak = s_x[p];
+  const bool dem = P + 119ll * sps + half < a.dem_hi;        // demod.py:76,82 (sps even)
+  float x1 = 0.0f, x0 = 0.0f, y1 = 0.0f, y0 = 0.0f;
+  if (dem) {                                                 // wave-uniform
+    auto smp = [&](int j) -> float { return (j < kWWin) ? s_x[j] : xg<MODE>(a.data, a.n, t0 + j, a.scale); };
+    const int j0 = p + 8 * sps + lane * sps;                 // demod.py:75,87
+    x1 = smp(j0); x0 = smp(j0 + half);                       // demod.py:91
+    if (lane < 48) { y1 = smp(j0 + 64 * sps); y0 = smp(j0 + 64 * sps + half); }
+  }
+  const ParityConsts pc = parity_consts(lane);
+  burst_reduce(a.origin + P, nwin, val0, val1, peak, v0, v1, dem, x1, x0, y1, y0, xflags, out, lane, pc);
 }
 
 // ---- global -> register -> LDS staging of one wavefront's share of a span ----------------------------
@@ -509,7 +552,7 @@ __device__ __forceinline__ void span_commit(Span<MODE, COUNT, NWAVES>& sp, float
       m.y = mag2f(sp.q[k].z, sp.q[k].w);
       if (REISSUE > 0 && k < REISSUE) sp.q[k] = *reinterpret_cast<const Q*>(next + (k * 64 * (int)sizeof(Q) + lo));
       if (act) *reinterpret_cast<float2*>(&sx[g + 2 * lane]) = m;
-      if (!kNoMasks) {
+      {
         // lane l holds samples 2l, 2l+1: the even/odd threshold masks (framer.py:83-84) are interleaved into
         // natural-order words on the SCALAR unit: s_bitreplicate doubles every bit, the masks pick the slot
         const unsigned long long E = __ballot(act && m.x >= thr), O = __ballot(act && m.y >= thr);
@@ -541,7 +584,7 @@ __device__ __forceinline__ void span_commit(Span<MODE, COUNT, NWAVES>& sp, float
       }
       if (REISSUE > 0 && k < REISSUE) sp.q[k] = *reinterpret_cast<const Q*>(next + (k * 64 * (int)sizeof(Q) + lo));
       if (act) *reinterpret_cast<float4*>(&sx[g + 4 * lane]) = m;
-      if (!kNoMasks) {
+      {
         const unsigned long long A = __ballot(act && m.x >= thr), B = __ballot(act && m.y >= thr);
         const unsigned long long C = __ballot(act && m.z >= thr), D = __ballot(act && m.w >= thr);
         const int c = lane & 3;
@@ -575,12 +618,12 @@ __device__ __forceinline__ void span_commit(Span<MODE, COUNT, NWAVES>& sp, float
 // ordering across units is by unit index (k_scan / k_gather).
 template <int MODE>
 __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_xa[kWaves][kWWin];
+  __shared__ __attribute__((aligned(16))) float s_xa[kWaves][kBack + kWWin];
   __shared__ unsigned long long s_maska[kWaves][kWWords];
   __shared__ unsigned s_risea[kWaves][kWTile / 2];
 
   const int lane = threadIdx.x & 63, wave = adsb_uniform((int)(threadIdx.x >> 6));
-  float* s_x = s_xa[wave];
+  float* s_x = s_xa[wave] + kBack;                           // s_x[j] <-> sample t0 + j, j in [-kBack, kWWin)
   unsigned long long* s_mask = s_maska[wave];
   unsigned* s_rise = s_risea[wave];
   const long long unit = (long long)blockIdx.x * kWaves + wave;
@@ -593,6 +636,7 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
   unsigned uflags = 0u;
   int pred = adsb_uniform(above_at<MODE>(a, c0 - 1) ? 1 : 0);
   unsigned long long* my_cands = a.cands + unit * a.rec_cap;
+  Rec* my_recs = a.recs + unit * a.rec_cap;
 
   // virtual rise in the zero history in front of a fresh stream: only possible when 0 >= thr
   if (unit == 0 && a.scan_lo < 0 && (0.0f >= a.thr) && !(a.prev_in0 >= a.thr)) {
@@ -613,9 +657,17 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
     body_ok = span_issue(body, a, c0 + kFwd, 0, lane);
     if (head_ok) span_commit(head, s_x, s_mask, 0, a.thr, a.scale, 0, lane);
     else span_fill_ragged_w<MODE, kFwd>(s_x, s_mask, 0, a, c0, lane);
+    // back halo of the first tile (later tiles inherit it from their predecessor): once per unit and launch
+    for (int i = lane; i < kBack; i += 64) s_x[i - kBack] = xg<MODE>(a.data, a.n, c0 - kBack + i, a.scale);
   }
 
+  const int lane_outer = lane;
   for (long long t0 = c0; t0 < c1; t0 += kWTile) {
+    // The lane number through an opaque copy, renewed every tile: otherwise a dozen lane-derived addresses and masks
+    // (64-bit offsets of the loads, LDS addresses, 64*j + lane ...) are hoisted out of this loop as loop-invariant
+    // registers, which the 96-VGPR budget of five resident wavefronts per SIMD cannot hold (they were spilled to
+    // scratch memory, and every reload waited for the prefetch of the next tile with it).
+    const int lane = adsb_opaque(lane_outer);
     // -- A: commit this tile's body (floats + mask words 4..19), start fetching the next one
     if (!body_ok) {
       span_fill_ragged_w<MODE, kWTile>(s_x, s_mask, kFwd, a, t0 + kFwd, lane);
@@ -632,14 +684,14 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
 
     // -- B.1 rises / falls by mask algebra (framer.py:91-93); lanes 0..15 own one word each
     const int word = (lane < kWWords) ? lane : 0;          // lanes 0..19 hold words 0..19 (16..19 = forward halo)
-    const unsigned long long M = kNoMasks ? 0ull : s_mask[word];
-    const unsigned long long pb = kNoMasks ? 0ull : (word > 0) ? (s_mask[word - 1] >> 63) : (unsigned long long)pred;
+    const unsigned long long M = s_mask[word];
+    const unsigned long long pb = (word > 0) ? (s_mask[word - 1] >> 63) : (unsigned long long)pred;
     const unsigned long long sh = (M << 1) | pb;
     const long long wbase = t0 + 64ll * word;
     const unsigned long long own = (lane < 16) ? bit_range(a.scan_lo - wbase, a.scan_hi - wbase) : 0ull;
     unsigned long long R = M & ~sh & own;
     const unsigned long long Fm = ~M & sh & own;
-    const unsigned long long anyr = (kAblate >= 2 && kAblate < 20) ? 0ull : __ballot(R != 0ull), anyf = __ballot(Fm != 0ull);
+    const unsigned long long anyr = __ballot(R != 0ull), anyf = __ballot(Fm != 0ull);
     uflags |= (anyr ? 1u : 0u) | (anyf ? 2u : 0u);
     int nm = 0;
     if (anyr) {                                            // wave-uniform: quiet stretches skip everything below
@@ -671,7 +723,6 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
         }
       }
       adsb_wave_sync();
-      if (kAblate == 21) nr = 0;                           // (tuning aid: list built, nothing evaluated)
 
       // -- B.2 per rise: fall, centre, 16-chip test (framer.py:113,137-147)
       int lp = -1, lp2 = -1, hflag = 0;
@@ -694,9 +745,7 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
           if (i == nr - 1) lp = p;                         // centres increase with i; only the last rise of
           else if (i == nr - 2) lp2 = p;                   // a tile can be left without a fall
           unsigned chips = 0;
-          if (kAblate == 22) { chips = (unsigned)p & 1u; }  // (tuning aid: no taps)
-          else if (kAblate == 24) { chips = (i == 0) ? kTemplate : 0u; }   // (tuning aid: no taps, one match per tile)
-          else if (p + 15 * half < kWWin) {                // all 16 taps inside the LDS window: one LDS round trip
+          if (p + 15 * half < kWWin) {                // all 16 taps inside the LDS window: one LDS round trip
             const float* tp = s_x + p;
             float tap[16];
 #pragma unroll
@@ -713,8 +762,7 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
               chips |= (v > hp ? 1u : 0u) << k;
             }
           }
-          if (kAblate == 23) { if (chips == kTemplate) hflag |= 8; }   // (tuning aid: taps read and used, no match kept)
-          else if (chips == kTemplate) {
+          if (chips == kTemplate) {
             res = 0x8000u | (unsigned)p;
             if (a.long_aware) {                              // first data bit (demod.py:87-95, k = 0): DF >= 16 = long reply
               const int i1 = p + 16 * half, i0 = i1 + half;
@@ -748,12 +796,15 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
       }
       adsb_wave_sync();
 
-      // -- C: append to this unit's list (stream order by construction)
-      for (int i = lane; i < nm; i += 64) {
-        const unsigned e = s_rise[i];
-        const int slot = nrec + i;
-        if (slot < a.rec_cap) {
-          if (e == 0xFFFFu) {
+      // -- C: this tile's matches, in stream order: the list word and, built by the whole wavefront from the LDS
+      //    window while it still holds the burst's samples, the burst record (wave-uniform loop: a tile rarely has
+      //    more than one or two matches)
+      for (int m = 0; m < nm; ++m) {
+        const int slot = nrec + m;
+        if (slot >= a.rec_cap) break;                        // overflow: reported through the count, call is re-run
+        const unsigned e = (unsigned)adsb_uniform((int)s_rise[m]);
+        if (e == 0xFFFFu) {
+          if (lane == 0) {
             // the long pulse is the last rise of its tile: recover its index from the masks
             long long rg = kNoIndex;
             for (int w2 = kWOwn - 1; w2 >= 0 && rg == kNoIndex; --w2) {
@@ -766,24 +817,39 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
             my_cands[slot] = cand_make(rg, kPending | kNoMatch);
             const int li = atomicAdd(a.long_count, 1);
             if (li < a.long_cap) { LongRise le; le.rise = rg; le.blk = (int)unit; le.slot = slot; a.longlist[li] = le; }
-          } else {
-            my_cands[slot] = cand_make(t0 + (long long)(e & 0x7FFFu), (e & 0x10000u) ? kLongHint : 0u);
           }
+        } else {
+          const int p = (int)(e & 0x7FFFu);
+          const bool lh = (e & 0x10000u) != 0;
+          if (lane == 0) my_cands[slot] = cand_make(t0 + (long long)p, lh ? kLongHint : 0u);
+          burst_from_window<MODE>(WinArgs{a.data, a.n, a.in0_base, a.dem_hi, a.origin, a.scale, a.sps}, s_x, t0, p,
+                                  lh ? kRecLongHint : 0u, my_recs + slot, lane);
         }
       }
       nrec += nm;
     }
 
-    // what the next tile inherits: the forward halo (floats + mask words) and the last threshold bit
-    float keep[kFwd / 64];
-#pragma unroll
-    for (int j = 0; j < kFwd / 64; ++j) keep[j] = s_x[kWTile + lane + 64 * j];
+    // what the next tile inherits: back + forward halo (floats; mask words of the forward halo) and the last threshold bit
+    // (sources [kWTile-kBack, kWWin) and destinations [-kBack, kFwd) are disjoint: two short batches keep the
+    // register footprint of this step at four values)
     const unsigned long long keepm = (lane < kHeadWords) ? s_mask[kWOwn + lane] : 0ull;
     const int keepp = adsb_uniform((int)(s_mask[kWOwn - 1] >> 63));
-    adsb_wave_sync();
+    {
+      float keep[kFwd / 64];
 #pragma unroll
-    for (int j = 0; j < kFwd / 64; ++j) s_x[lane + 64 * j] = keep[j];
-    if (lane < kHeadWords) s_mask[lane] = keepm;
+      for (int j = 0; j < kFwd / 64; ++j) keep[j] = s_x[kWTile + lane + 64 * j];
+      adsb_wave_sync();
+#pragma unroll
+      for (int j = 0; j < kFwd / 64; ++j) s_x[lane + 64 * j] = keep[j];
+      if (lane < kHeadWords) s_mask[lane] = keepm;
+    }
+    {
+      float keepb[kBack / 64];
+#pragma unroll
+      for (int j = 0; j < kBack / 64; ++j) keepb[j] = s_x[kWTile - kBack + lane + 64 * j];
+#pragma unroll
+      for (int j = 0; j < kBack / 64; ++j) s_x[lane + 64 * j - kBack] = keepb[j];
+    }
     pred = keepp;
     // (the next iteration's commit writes s_x[kFwd..] and mask words >= 4; its wave_sync orders all of it)
   }
@@ -838,7 +904,12 @@ __global__ void __launch_bounds__(kThreads) k_longrun(DetectArgs a) {
           const long long i1 = p + 8ll * a.sps;
           if (xg<MODE>(a.data, a.n, i1, a.scale) > xg<MODE>(a.data, a.n, i1 + (a.sps >> 1), a.scale)) hint = kLongHint;
         }
-        if (lane == 0) *out = ((unsigned)cm == kTemplate) ? cand_make(p, hint) : cand_make(p, kNoMatch);
+        const bool match = (unsigned)cm == kTemplate;          // wave-uniform
+        if (lane == 0) *out = match ? cand_make(p, hint) : cand_make(p, kNoMatch);
+        if (match) {                                           // the centre's burst record, samples from global memory
+          const BurstFetch<MODE> bf = burst_issue<MODE>(a, cand_make(p, hint), lane);
+          burst_finish<MODE>(a, bf, a.recs + (long long)le.blk * a.rec_cap + le.slot, lane, parity_consts(lane));
+        }
       } else if (lane == 0) {
         *out = cand_make(le.rise, kNoMatch);
         if (!a.end_is_call_end) atomicOr(a.blk_flags + le.blk, 4u);
@@ -946,15 +1017,20 @@ __global__ void __launch_bounds__(kThreads) k_scan(const int* blk_count, const l
   }
 }
 
-// ---- k_gather: per-workgroup slices -> one list in stream order ------------------------------------
-__global__ void __launch_bounds__(kThreads) k_gather(const unsigned long long* cands, const int* blk_count,
+// ---- k_gather: per-unit lists (centre words + burst records) -> one list each in stream order --------
+__global__ void __launch_bounds__(kThreads) k_gather(const unsigned long long* cands, const Rec* recs, const int* blk_count,
                                                      const int* blk_off, int nblk, int rec_cap,
-                                                     unsigned long long* sorted) {
+                                                     unsigned long long* sorted, Rec* sorted_recs) {
   for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
     int c = blk_count[b];
     if (c > rec_cap) c = rec_cap;
     const int off = blk_off[b];
-    for (int j = threadIdx.x; j < c; j += kThreads) sorted[off + j] = cands[(long long)b * rec_cap + j];
+    const long long src = (long long)b * rec_cap;
+    for (int j = threadIdx.x; j < c; j += kThreads) sorted[off + j] = cands[src + j];
+    // records as 16-byte halves: consecutive threads touch consecutive 16 bytes
+    const RecHalf* rs = reinterpret_cast<const RecHalf*>(recs + src);
+    RecHalf* rd = reinterpret_cast<RecHalf*>(sorted_recs + off);
+    for (int j = threadIdx.x; j < 2 * c; j += kThreads) rd[j] = rs[j];
   }
 }
 
@@ -1030,9 +1106,10 @@ __global__ void __launch_bounds__(kThreads) k_count(const unsigned long long* so
 
 // k_compact also does what a separate single-workgroup scan kernel used to: every workgroup sums the segment counts
 // in front of its segment itself (a few hundred ints, L2 resident) -- one launch fewer on the tail of every pass.
-__global__ void __launch_bounds__(kThreads) k_compact(const unsigned long long* sorted, Summary* sum,
+// Emits the survivors' burst records (built by k_detect / k_longrun, ordered by k_gather) with kKept / kHead added.
+__global__ void __launch_bounds__(kThreads) k_compact(const unsigned long long* sorted, const Rec* sorted_recs, Summary* sum,
                                                       const int* seg_count, unsigned fmask, unsigned fwant, int head_n,
-                                                      unsigned long long* kept, int out_cap, int* long_count,
+                                                      Rec* out, int out_cap, int* long_count,
                                                       unsigned long long* long_lastp) {
   __shared__ int s_c[kWaves];
   __shared__ int s_pre[kWaves], s_tot[kWaves];
@@ -1067,41 +1144,19 @@ __global__ void __launch_bounds__(kThreads) k_compact(const unsigned long long* 
     off += lanes_below(m, lane);
     if (seg == 0 && threadIdx.x == 0) sum->n_kept = total;
     if (k && off < out_cap) {
-      kept[off] = c;
+      Rec r = sorted_recs[i];
+      r.w[3] |= (unsigned long long)(cand_flags(c) & (kKept | kHead)) << 48;
+      out[off] = r;
       if (off == total - 1) sum->last_kept_p = cand_p(c);
     }
     __syncthreads();
   }
 }
 
-// ---- k_burst: one wavefront per surviving centre -> the 32-byte burst record -------------------------
-template <int MODE>
-__global__ void __launch_bounds__(kThreads) k_burst(DetectArgs a, const unsigned long long* kept, const Summary* sum,
-                                                    Rec* out, int out_cap, Summary* host_sum) {
-  const int lane = threadIdx.x & 63;
-  const int wave_g = (int)((blockIdx.x * (unsigned)kThreads + threadIdx.x) >> 6);
-  const int nwave = (int)((gridDim.x * (unsigned)kThreads) >> 6);
-  // the pass's 48-byte summary is final before this kernel starts: one thread stores it straight into the caller-
-  // visible (pinned, mapped) host copy -- no separate copy operation on the tail of the pass
-  if (host_sum != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *host_sum = *sum;
-  int n = sum->n_kept;
-  if (n > out_cap) n = out_cap;
-  const ParityConsts pc = parity_consts(lane);
-  if (wave_g >= n) return;
-  // software pipeline over this wavefront's bursts: the gathers of burst t+1 and the list word of burst t+2
-  // are in flight while burst t is reduced (median select, slice, parity) -- otherwise every burst costs two
-  // dependent HBM round trips of an otherwise idle wavefront
-  BurstFetch<MODE> cur = burst_issue<MODE>(a, kept[wave_g], lane);
-  unsigned long long c1 = (wave_g + nwave < n) ? kept[wave_g + nwave] : 0ull;
-  for (int t = wave_g; t < n; t += nwave) {
-    const int tn = t + nwave, t2 = tn + nwave;
-    BurstFetch<MODE> nxt = cur;
-    if (tn < n) nxt = burst_issue<MODE>(a, c1, lane);
-    const unsigned long long c2 = (t2 < n) ? kept[t2] : 0ull;
-    burst_finish<MODE>(a, cur, out + t, lane, pc);
-    cur = nxt;
-    c1 = c2;
-  }
+// ---- k_publish: the pass's 48-byte summary, final once k_compact is done, stored straight into the caller-visible
+// (pinned, mapped) host copy -- no separate copy operation on the tail of the pass
+__global__ void k_publish(const Summary* sum, Summary* host_sum) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *host_sum = *sum;
 }
 
 // ---- k_slice: PPM slice (+ optional confidence ratio) for a caller-supplied tag list ---------------
@@ -1118,7 +1173,8 @@ __global__ void __launch_bounds__(kThreads) k_slice(const void* data, long long 
   const ParityConsts pc = parity_consts(lane);
   for (int t = wave_g; t < ntags; t += nwave) {
     const long long p = tag_idx[t];
-    const bool dem = p + 119ll * sps + half < n;
+    // demod.work() only ever sees tags inside its own chunk (demod.py:67): a tag in front of it is dropped, not sliced
+    const bool dem = p >= 0 && p + 119ll * sps + half < n;
     bool b0 = false, b1 = false;
     float q0 = 0.0f, q1 = 0.0f;
     if (dem) {
@@ -1143,6 +1199,35 @@ __global__ void __launch_bounds__(kThreads) k_slice(const void* data, long long 
     if (ratio && dem) {
       ratio[(long long)t * 112 + lane] = q0;
       if (lane < 48) ratio[(long long)t * 112 + 64 + lane] = q1;
+    }
+  }
+}
+
+// ---- k_confidence: opt-in confidence output of the fused path (ADSB_FLAG_CONFIDENCE) -----------------
+// demod.py:97-101 keeps bit_confidence = 10*log10(bit1_amp / bit0_amp) for the burst it just sliced; this kernel
+// returns the float32 RATIO of every delivered record that has a PDU (the host applies 10*log10 with NumPy, like the
+// SNR): one wavefront per record, samples from global memory, row t of ratio[n_kept][112] belongs to record t
+// (rows of records without ADSB_BURST_DEMOD are left untouched).
+template <int MODE>
+__global__ void __launch_bounds__(kThreads) k_confidence(DetectArgs a, const Rec* out, const Summary* sum, int out_cap,
+                                                         float* ratio) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = (int)((blockIdx.x * (unsigned)kThreads + threadIdx.x) >> 6);
+  const int nwave = (int)((gridDim.x * (unsigned)kThreads) >> 6);
+  int n = sum->n_kept;
+  if (n > out_cap) n = out_cap;
+  const int sps = a.sps, half = sps >> 1;
+  for (int t = wave_g; t < n; t += nwave) {
+    const Rec r = out[t];
+    if (!((unsigned)(r.w[3] >> 48) & kDemod)) continue;        // wave-uniform
+    const long long p = (long long)r.w[0] - a.origin;
+    const long long s0 = p + 8ll * sps + (long long)lane * sps;
+    const float x1 = xg<MODE>(a.data, a.n, s0, a.scale), x0 = xg<MODE>(a.data, a.n, s0 + half, a.scale);
+    ratio[(long long)t * 112 + lane] = __fdiv_rn(x1, x0);
+    if (lane < 48) {
+      const long long s1 = s0 + 64ll * sps;
+      const float y1 = xg<MODE>(a.data, a.n, s1, a.scale), y0 = xg<MODE>(a.data, a.n, s1 + half, a.scale);
+      ratio[(long long)t * 112 + 64 + lane] = __fdiv_rn(y1, y0);
     }
   }
 }

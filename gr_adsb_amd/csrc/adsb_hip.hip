@@ -1,7 +1,11 @@
 // adsb_hip.hip -- host side of libadsb_hip.so (C ABI in include/adsb_hip.h) for gfx950.
 // Owns device memory, pinned staging and the launch sequence
-//   k_detect -> k_scan -> k_gather -> k_resolve -> k_count -> k_compact -> k_burst  (+ k_longrun when needed)
+//   k_detect (the one pass over the samples: centres AND their burst records) -> k_longrun (no-op unless needed)
+//   -> k_scan -> k_gather -> k_resolve -> k_count -> k_compact -> k_publish          (sparse lists only)
 // There is deliberately no CPU implementation of the path in this library.
+//
+// Tuning knobs exist only in side copies built with -DADSB_TUNING (tools/kbench.py); the shipped library reads no
+// environment variable.
 #include <hip/hip_runtime.h>
 
 #include <cerrno>
@@ -21,6 +25,11 @@ __device__ __forceinline__ void adsb_wave_sync() {
 
 __device__ __forceinline__ int adsb_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int adsb_readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// the value itself, but opaque to the optimiser (per-lane: a vector register)
+__device__ __forceinline__ int adsb_opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 // bit i of x -> bits 2i and 2i+1 (scalar unit; the argument must be wave-uniform)
 __device__ __forceinline__ unsigned long long adsb_bitrep32(unsigned x) {
   unsigned long long r;
@@ -52,14 +61,19 @@ struct Misc {
   Summary sum;
 };
 
-// Everything one in-flight call needs on the device and in pinned host memory.  Two slots let call i+1
-// run on the GPU while the records of call i travel over PCIe (adsb_submit_* / adsb_wait).
+// Everything one in-flight call needs on the device and in pinned host memory.  Several slots let call i+1
+// run on the GPU while the records of call i travel over PCIe (adsb_submit_* / adsb_wait), and -- host-fed -- while
+// the samples of call i+2 travel the other way.
 struct Slot {
-  DevBuf d_cands, d_sorted, d_kept, d_out, d_seg, d_blk_count, d_blk_lastp, d_blk_flags, d_blk_off, d_long, d_misc;
+  DevBuf d_cands, d_recs, d_sorted, d_sorted_recs, d_out, d_seg, d_blk_count, d_blk_lastp, d_blk_flags, d_blk_off, d_long, d_misc;
+  DevBuf d_in;                   // host-fed submissions: this call's samples (adsb_submit_format_host)
+  DevBuf d_ratio;                // ADSB_FLAG_CONFIDENCE: [n_kept][112] bit1/bit0 ratios
   Summary* h_sum = nullptr;      // pinned
   void* h_out = nullptr;         // pinned burst records of the finished call
   size_t h_out_cap = 0;
-  hipEvent_t done = nullptr, ev0 = nullptr, ev1 = nullptr, det_done = nullptr;
+  void* h_ratio = nullptr;       // pinned confidence ratios of the finished call
+  size_t h_ratio_cap = 0;
+  hipEvent_t done = nullptr, ev0 = nullptr, ev1 = nullptr, det_done = nullptr, h2d_done = nullptr;
   bool busy = false;
   bool is_shard = false;
   bool ev1_valid = false;
@@ -80,7 +94,8 @@ struct adsb_ctx {
   uint32_t flags = 0;
   hipStream_t stream = nullptr;       // compute
   hipStream_t copy_stream = nullptr;  // device -> pinned host result copies
-  hipStream_t tail_stream = nullptr;  // everything after k_detect/k_longrun (may overlap the next pass's k_detect)
+  hipStream_t tail_stream = nullptr;  // everything after k_detect (may overlap the next pass's k_detect)
+  hipStream_t h2d_stream = nullptr;   // host-fed submissions: sample uploads, back to back on their own stream
   bool split_tail = false;
   bool own_stream = false;
   int n_cu = 256;
@@ -93,8 +108,14 @@ struct adsb_ctx {
   int last_slot = 0;
   DevBuf d_in, d_tags, d_bits, d_ok, d_ratio;
   int rec_cap_shift = 0;  // rec_cap multiplier (grows on overflow)
-  void* h_stage = nullptr;
+  void* h_stage = nullptr;   // pinned staging for pageable inputs of the blocking entry points
   size_t h_stage_cap = 0;
+  void* h_dm = nullptr;      // pinned scratch of adsb_demod_work: tag positions in, bits / ok / ratio out
+  size_t h_dm_cap = 0;
+  void* h_ring[2] = {nullptr, nullptr};   // pinned chunks for pageable host-fed submissions (double buffered)
+  hipEvent_t ring_done[2] = {nullptr, nullptr};
+  bool ring_used[2] = {false, false};
+  unsigned ring_k = 0;
   adsb_stats stats{};
   char err[256] = {0};
 };
@@ -143,11 +164,16 @@ int ensure_pinned(adsb_ctx* c, void*& p, size_t& cap, size_t bytes) {
     default: F<4>(__VA_ARGS__); break;        \
   }
 
+#ifdef ADSB_TUNING
+// side copies for kernel tuning only (tools/kbench.py): integer knobs from the environment
+int tune_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+constexpr int tune_int(const char*, int dflt) { return dflt; }
+#endif
+
 template <int MODE>
 void launch_detect(adsb_ctx* c, const DetectArgs& a, int grid) {
-  // ADSB_DEBUG_DYNLDS (bytes): tuning knob that pads the workgroup's LDS to lower occupancy on purpose
-  static const int dyn = getenv("ADSB_DEBUG_DYNLDS") ? atoi(getenv("ADSB_DEBUG_DYNLDS")) : 0;
-  hipLaunchKernelGGL((k_detect<MODE>), dim3(grid), dim3(kThreads), dyn, c->stream, a);
+  hipLaunchKernelGGL((k_detect<MODE>), dim3(grid), dim3(kThreads), 0, c->stream, a);
 }
 template <int MODE>
 int detect_occupancy() {
@@ -157,25 +183,12 @@ int detect_occupancy() {
   return nb;
 }
 template <int MODE>
-void launch_burst(adsb_ctx* c, hipStream_t st, const DetectArgs& a, const unsigned long long* kept, const Summary* sum,
-                  Rec* out, int cap, Summary* host_sum) {
-  static const int bg = getenv("ADSB_DEBUG_BURST_GRID") ? atoi(getenv("ADSB_DEBUG_BURST_GRID")) : 8;   // tuning probe: workgroups per CU
-  hipLaunchKernelGGL((k_burst<MODE>), dim3(c->n_cu * bg), dim3(kThreads), 0, st, a, kept, sum, out, cap, host_sum);
-}
-template <int MODE>
 void launch_longrun(hipStream_t st, const DetectArgs& a) {
   hipLaunchKernelGGL((k_longrun<MODE>), dim3(64), dim3(kThreads), 0, st, a);
 }
-
-// tuning probe (ADSB_DEBUG_DUMMY=<blocks>,<microseconds>): a kernel that only spins, in place of the tail
-__global__ void k_dummy(long long ticks, const int* rd, int* wr, int mode) {
-  const long long t0 = wall_clock64();
-  int acc = 0;
-  while (wall_clock64() - t0 < ticks) {
-    __builtin_amdgcn_s_sleep(8);
-    if (mode & 1) acc += __builtin_nontemporal_load(rd + ((threadIdx.x * 16 + (int)(wall_clock64() & 1023)) % 5000));
-  }
-  if ((mode & 2) || acc == 0x7fffffff) wr[threadIdx.x] = acc;
+template <int MODE>
+void launch_confidence(hipStream_t st, int grid, const DetectArgs& a, const Rec* out, const Summary* sum, int cap, float* ratio) {
+  hipLaunchKernelGGL((k_confidence<MODE>), dim3(grid), dim3(kThreads), 0, st, a, out, sum, cap, ratio);
 }
 
 // Everything after k_detect (and after k_longrun on the rare second pass): order, gate, compact, records.
@@ -194,40 +207,31 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
     HIPCHK(c, hipStreamWaitEvent(c->tail_stream, dep, 0));
     ts = c->tail_stream;
   }
-  // tuning probe ADSB_DEBUG_TAIL_MASK: launch only the tail stages whose bit is set (results are garbage then):
-  // 1 longrun, 2 scan, 4 gather, 8 resolve, 16 count, 64 compact, 128 burst, 256 summary copy
-  static const unsigned tm = getenv("ADSB_DEBUG_TAIL_MASK") ? (unsigned)strtoul(getenv("ADSB_DEBUG_TAIL_MASK"), nullptr, 0) : ~0u;
-  static const char* dummy = getenv("ADSB_DEBUG_DUMMY");
-  if (dummy) {
-    int nb = 1, us = 100, mode = 0;
-    sscanf(dummy, "%d,%d,%d", &nb, &us, &mode);
-    hipLaunchKernelGGL(k_dummy, dim3(nb), dim3(kThreads), 0, ts, (long long)us * 100, (const int*)a.blk_count,
-                       (int*)s.d_blk_off.p, mode);   // wall clock: 100 MHz
-  }
   // no-op unless k_detect listed pulses longer than its LDS window
-  if (tm & 1) ADSB_BY_MODE(pl.mode, launch_longrun, ts, a);
-  if (tm & 2) hipLaunchKernelGGL(k_scan, dim3(1), dim3(kThreads), 0, ts, (const int*)a.blk_count,
+  ADSB_BY_MODE(pl.mode, launch_longrun, ts, a);
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(kThreads), 0, ts, (const int*)a.blk_count,
                      (const long long*)a.blk_lastp, (const unsigned*)a.blk_flags, s.nlists, s.rec_cap,
                      (const int*)a.long_count, (const unsigned long long*)a.long_lastp, (int*)s.d_blk_off.p, &misc->sum);
   const int gg = s.nlists < 1024 ? s.nlists : 1024;
   unsigned long long* sorted = (unsigned long long*)s.d_sorted.p;
-  unsigned long long* kept = (unsigned long long*)s.d_kept.p;
-  if (tm & 4) hipLaunchKernelGGL(k_gather, dim3(gg), dim3(kThreads), 0, ts, (const unsigned long long*)a.cands,
-                     (const int*)a.blk_count, (const int*)s.d_blk_off.p, s.nlists, s.rec_cap, sorted);
+  Rec* sorted_recs = (Rec*)s.d_sorted_recs.p;
+  hipLaunchKernelGGL(k_gather, dim3(gg), dim3(kThreads), 0, ts, (const unsigned long long*)a.cands, (const Rec*)a.recs,
+                     (const int*)a.blk_count, (const int*)s.d_blk_off.p, s.nlists, s.rec_cap, sorted, sorted_recs);
   const int ag = 512;
   unsigned fmask = 0u, fwant = 0u;
   if (pl.gate) {
-    if (tm & 8) hipLaunchKernelGGL(k_resolve, dim3(ag), dim3(kThreads), 0, ts, sorted, (const Summary*)&misc->sum,
+    hipLaunchKernelGGL(k_resolve, dim3(ag), dim3(kThreads), 0, ts, sorted, (const Summary*)&misc->sum,
                        (long long)63 * c->sps, (long long)(pl.long_aware ? 119 : 63) * c->sps, pl.prev_eob_stream - pl.origin);
     fmask = kKept; fwant = kKept;
   }
-  if (tm & 16) hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted,
+  hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted,
                      (const Summary*)&misc->sum, fmask, fwant, pl.head_n, (int*)s.d_seg.p);
-  if (tm & 64) hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted, &misc->sum,
-                     (const int*)s.d_seg.p, fmask, fwant, pl.head_n, kept, (int)s.tot, a.long_count, a.long_lastp);
-  // k_burst also stores the summary into s.h_sum (pinned host memory, device-visible): visible to the host once
-  // the `done` event below has completed
-  if (tm & 128) ADSB_BY_MODE(pl.mode, launch_burst, c, ts, a, kept, &misc->sum, (Rec*)s.d_out.p, (int)s.tot, s.h_sum);
+  hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted, (const Rec*)sorted_recs,
+                     &misc->sum, (const int*)s.d_seg.p, fmask, fwant, pl.head_n, (Rec*)s.d_out.p, (int)s.tot, a.long_count,
+                     a.long_lastp);
+  // the summary goes straight into s.h_sum (pinned host memory, device-visible): visible to the host once the `done`
+  // event below has completed
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ts, (const Summary*)&misc->sum, s.h_sum);
   HIPCHK(c, hipEventRecord(s.done, ts));
   return 0;
 }
@@ -243,9 +247,8 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   const int tile = kWTile;
   long long ntiles = (s.span + tile - 1) / tile;
   if (ntiles < 1) ntiles = 1;
-  static const int bpc_env = getenv("ADSB_DEBUG_BPC") ? atoi(getenv("ADSB_DEBUG_BPC")) : 0;
-  static const int slack_env = getenv("ADSB_DEBUG_GRID_SLACK") ? atoi(getenv("ADSB_DEBUG_GRID_SLACK")) : 0;   // tuning probe
-  const long long umax = ((long long)c->n_cu * (bpc_env > 0 ? bpc_env : c->bpc[pl.mode]) - slack_env) * upb;
+  const int bpc = tune_int("ADSB_TUNE_BPC", c->bpc[pl.mode]);
+  const long long umax = ((long long)c->n_cu * bpc - tune_int("ADSB_TUNE_GRID_SLACK", 0)) * upb;
   long long units = ntiles < umax ? ntiles : umax;
   const long long tiles_per = (ntiles + units - 1) / units;
   units = (ntiles + tiles_per - 1) / tiles_per;
@@ -258,8 +261,9 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   const long long long_cap = ntiles + 1;        // at most one long pulse per tile, plus the virtual rise
   int r;
   if ((r = ensure(c, s.d_cands, (size_t)s.tot * 8))) return r;
+  if ((r = ensure(c, s.d_recs, (size_t)s.tot * sizeof(Rec)))) return r;
   if ((r = ensure(c, s.d_sorted, (size_t)s.tot * 8))) return r;
-  if ((r = ensure(c, s.d_kept, (size_t)s.tot * 8))) return r;
+  if ((r = ensure(c, s.d_sorted_recs, (size_t)s.tot * sizeof(Rec)))) return r;
   if ((r = ensure(c, s.d_out, (size_t)s.tot * sizeof(Rec)))) return r;
   if ((r = ensure(c, s.d_seg, (size_t)(s.tot / kThreads + 2) * sizeof(int)))) return r;
   if ((r = ensure(c, s.d_blk_count, (size_t)nlists * sizeof(int)))) return r;
@@ -280,7 +284,7 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   a.fall_hi = pl.fall_hi; a.dem_hi = pl.dem_hi; a.origin = pl.origin; a.chunk = chunk; a.thr = c->thr;
   a.prev_in0 = pl.prev_in0; a.scale = c->scale[pl.mode]; a.sps = c->sps; a.end_is_call_end = pl.end_is_call_end; a.rec_cap = s.rec_cap;
   a.long_aware = pl.long_aware ? 1 : 0;
-  a.long_cap = (int)long_cap; a.cands = (unsigned long long*)s.d_cands.p; a.blk_count = (int*)s.d_blk_count.p;
+  a.long_cap = (int)long_cap; a.cands = (unsigned long long*)s.d_cands.p; a.recs = (Rec*)s.d_recs.p; a.blk_count = (int*)s.d_blk_count.p;
   a.blk_lastp = (long long*)s.d_blk_lastp.p; a.blk_flags = (unsigned*)s.d_blk_flags.p;
   a.longlist = (LongRise*)s.d_long.p; a.long_count = &misc->long_count; a.long_lastp = &misc->long_lastp;
 
@@ -337,10 +341,22 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
     const int nres = sum->n_kept;
     int r = ensure_pinned(c, s.h_out, s.h_out_cap, (size_t)(nres > 0 ? nres : 1) * sizeof(Rec));
     if (r) { s.busy = false; return r; }
-    static const bool skip_d2h = getenv("ADSB_DEBUG_SKIP_D2H") != nullptr;   // tuning probe: records are not delivered
-    if (nres > 0 && !skip_d2h) {
+    if (nres > 0) {
       HIPCHK(c, hipMemcpyAsync(s.h_out, s.d_out.p, (size_t)nres * sizeof(Rec), hipMemcpyDeviceToHost, c->copy_stream));
+      if (c->flags & ADSB_FLAG_CONFIDENCE) {
+        // opt-in (demod.py:97-101): bit1/bit0 ratios of the delivered records, computed now that their number is
+        // known -- one more small kernel and copy on the copy stream, paid only by callers who ask for it
+        const size_t rb = (size_t)nres * 112 * sizeof(float);
+        if ((r = ensure(c, s.d_ratio, rb)) || (r = ensure_pinned(c, s.h_ratio, s.h_ratio_cap, rb))) { s.busy = false; return r; }
+        HIPCHK(c, hipMemsetAsync(s.d_ratio.p, 0, rb, c->copy_stream));
+        int cg = (nres + kWaves - 1) / kWaves;
+        if (cg > c->n_cu * 8) cg = c->n_cu * 8;
+        ADSB_BY_MODE(s.plan.mode, launch_confidence, c->copy_stream, cg, s.args, (const Rec*)s.d_out.p,
+                     (const Summary*)&((Misc*)s.d_misc.p)->sum, nres, (float*)s.d_ratio.p);
+        HIPCHK(c, hipMemcpyAsync(s.h_ratio, s.d_ratio.p, rb, hipMemcpyDeviceToHost, c->copy_stream));
+      }
       HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+      HIPCHK(c, hipGetLastError());
     }
     s.nres = nres;
     *n_res = nres;
@@ -462,13 +478,17 @@ int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx
   c->own_stream = true;
   if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { adsb_destroy(c); return -EIO; }
   if (hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking) != hipSuccess) { adsb_destroy(c); return -EIO; }
-  // on by default (measured +7 % whole-pass throughput with two passes in flight); ADSB_TAIL_STREAM=0 turns it off
-  c->split_tail = !(getenv("ADSB_TAIL_STREAM") && atoi(getenv("ADSB_TAIL_STREAM")) == 0);
+  if (hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking) != hipSuccess) { adsb_destroy(c); return -EIO; }
+  // the sparse tail of a pass runs on its own stream beside the next pass's k_detect unless the caller opts out
+  c->split_tail = (flags & ADSB_FLAG_SINGLE_STREAM) == 0;
+  for (hipEvent_t& e : c->ring_done)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { adsb_destroy(c); return -EIO; }
   for (Slot& sl : c->slot) {
     if (hipHostMalloc((void**)&sl.h_sum, sizeof(Summary), hipHostMallocDefault) != hipSuccess) { adsb_destroy(c); return -ENOMEM; }
     if (hipEventCreate(&sl.ev0) != hipSuccess || hipEventCreate(&sl.ev1) != hipSuccess ||
         hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&sl.det_done, hipEventDisableTiming) != hipSuccess) { adsb_destroy(c); return -EIO; }
+        hipEventCreateWithFlags(&sl.det_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming) != hipSuccess) { adsb_destroy(c); return -EIO; }
   }
   *out = c;
   return 0;
@@ -479,22 +499,30 @@ void adsb_destroy(adsb_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+  if (c->h2d_stream) (void)hipStreamSynchronize(c->h2d_stream);
+  if (c->tail_stream) (void)hipStreamSynchronize(c->tail_stream);
   DevBuf* bufs[] = {&c->d_in, &c->d_tags, &c->d_bits, &c->d_ok, &c->d_ratio};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (Slot& sl : c->slot) {
-    DevBuf* sb[] = {&sl.d_cands, &sl.d_sorted, &sl.d_kept, &sl.d_out, &sl.d_seg, &sl.d_blk_count, &sl.d_blk_lastp,
-                    &sl.d_blk_flags, &sl.d_blk_off, &sl.d_long, &sl.d_misc};
+    DevBuf* sb[] = {&sl.d_cands, &sl.d_recs, &sl.d_sorted, &sl.d_sorted_recs, &sl.d_out, &sl.d_seg, &sl.d_blk_count,
+                    &sl.d_blk_lastp, &sl.d_blk_flags, &sl.d_blk_off, &sl.d_long, &sl.d_misc, &sl.d_in, &sl.d_ratio};
     for (DevBuf* b : sb) if (b->p) (void)hipFree(b->p);
     if (sl.h_sum) (void)hipHostFree(sl.h_sum);
     if (sl.h_out) (void)hipHostFree(sl.h_out);
+    if (sl.h_ratio) (void)hipHostFree(sl.h_ratio);
+    if (sl.h2d_done) (void)hipEventDestroy(sl.h2d_done);
     if (sl.ev0) (void)hipEventDestroy(sl.ev0);
     if (sl.ev1) (void)hipEventDestroy(sl.ev1);
     if (sl.done) (void)hipEventDestroy(sl.done);
     if (sl.det_done) (void)hipEventDestroy(sl.det_done);
   }
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->h_dm) (void)hipHostFree(c->h_dm);
+  for (void* r : c->h_ring) if (r) (void)hipHostFree(r);
+  for (hipEvent_t e : c->ring_done) if (e) (void)hipEventDestroy(e);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-  if (c->tail_stream) { (void)hipStreamSynchronize(c->tail_stream); (void)hipStreamDestroy(c->tail_stream); }
+  if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
+  if (c->tail_stream) (void)hipStreamDestroy(c->tail_stream);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -593,7 +621,7 @@ int adsb_process_mag2(adsb_ctx* c, const float* mag2_host, int64_t n, int64_t ab
   return canonical(c, 1, d, n, abs_offset, out, cap, n_out);
 }
 
-static int shard_post(adsb_ctx* c, Slot& s, const Summary& sum, int32_t nres, bool drop_overlong = false);
+static int shard_post(adsb_ctx* c, Slot& s, const Summary& sum, int32_t* nres_io, bool drop_overlong = false);
 
 static int submit_canonical(adsb_ctx* c, int mode, const void* d_data, int64_t n, int64_t abs_offset, int32_t* ticket) {
   if (!c || n < 1 || !ticket) return -EINVAL;
@@ -607,6 +635,52 @@ static int submit_canonical(adsb_ctx* c, int mode, const void* d_data, int64_t n
   s.is_shard = false;
   *ticket = c->next_slot;
   c->next_slot = (c->next_slot + 1) % ADSB_MAX_IN_FLIGHT;
+  return 0;
+}
+
+// Host buffer -> the slot's own device input buffer on the upload stream; only this slot's k_detect waits for it.
+// Page-locked sources are DMA'd where they lie; pageable ones go through two pinned chunks, the CPU copy of chunk k+1
+// running beside the DMA of chunk k.
+static int upload_async(adsb_ctx* c, Slot& s, const void* host, size_t bytes) {
+  int rc;
+  if ((rc = ensure(c, s.d_in, bytes + 64))) return rc;
+  if (is_pinned_host(host)) {
+    HIPCHK(c, hipMemcpyAsync(s.d_in.p, host, bytes, hipMemcpyHostToDevice, c->h2d_stream));
+  } else {
+    constexpr size_t kChunk = (size_t)16 << 20;
+    for (void*& r : c->h_ring)
+      if (!r) HIPCHK(c, hipHostMalloc(&r, kChunk, hipHostMallocDefault));
+    for (size_t off = 0; off < bytes; off += kChunk) {
+      const size_t m = bytes - off < kChunk ? bytes - off : kChunk;
+      const int b = c->ring_k++ & 1;
+      if (c->ring_used[b]) HIPCHK(c, hipEventSynchronize(c->ring_done[b]));      // the chunk's previous DMA has read it
+      memcpy(c->h_ring[b], (const char*)host + off, m);
+      HIPCHK(c, hipMemcpyAsync((char*)s.d_in.p + off, c->h_ring[b], m, hipMemcpyHostToDevice, c->h2d_stream));
+      HIPCHK(c, hipEventRecord(c->ring_done[b], c->h2d_stream));
+      c->ring_used[b] = true;
+    }
+  }
+  HIPCHK(c, hipEventRecord(s.h2d_done, c->h2d_stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, s.h2d_done, 0));
+  return 0;
+}
+
+int adsb_submit_format_host(adsb_ctx* c, int format, const void* host, int64_t n, int64_t abs_offset, int32_t* ticket) {
+  if (!c || format < 0 || format >= ADSB_FMT_COUNT || n < 1 || !host || !ticket) return -EINVAL;
+  Slot& s = c->slot[c->next_slot];
+  if (s.busy) return fail(c, -EBUSY, "every pipeline slot is in flight (adsb_wait first)");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = upload_async(c, s, host, (size_t)n * (size_t)mode_bytes(format));
+  if (rc) return rc;
+  return submit_canonical(c, format, s.d_in.p, n, abs_offset, ticket);
+}
+
+int adsb_last_confidence(adsb_ctx* c, const float** ratio, int32_t* n) {
+  if (!c) return -EINVAL;
+  if (!(c->flags & ADSB_FLAG_CONFIDENCE)) return fail(c, -EINVAL, "context created without ADSB_FLAG_CONFIDENCE");
+  const Slot& s = c->slot[c->last_slot];
+  if (ratio) *ratio = s.nres > 0 ? (const float*)s.h_ratio : nullptr;
+  if (n) *n = s.nres;
   return 0;
 }
 
@@ -636,7 +710,7 @@ int adsb_wait(adsb_ctx* c, int32_t ticket, adsb_burst* out, int32_t cap, int32_t
   int r = finish(c, s, &sum, &nres);
   if (r) return r;
   c->last_slot = ticket;
-  if (s.is_shard && (r = shard_post(c, s, sum, nres))) return r;
+  if (s.is_shard && (r = shard_post(c, s, sum, &nres))) return r;
   return deliver(c, nres, out, cap, n_out);
 }
 
@@ -671,56 +745,74 @@ int adsb_demod_work(adsb_ctx* c, const float* in0, int64_t n, int64_t nitems_rea
                     int32_t ntags, uint8_t* bits112, uint8_t* ok, float* ratio) {
   if (!c || n < 0 || ntags < 0 || (n > 0 && !in0) || (ntags > 0 && (!tag_offsets || !bits112 || !ok))) return -EINVAL;
   if (ntags == 0) return 0;
+  for (const Slot& sl : c->slot) if (sl.busy) return fail(c, -EBUSY, "a submitted call is still pending (adsb_wait first)");
   HIPCHK(c, hipSetDevice(c->device));
-  void* d = nullptr;
-  int rc = upload(c, in0, (size_t)n * 4, &d);
-  if (rc) return rc;
-  if ((rc = ensure(c, c->d_tags, (size_t)ntags * 8))) return rc;
-  if ((rc = ensure(c, c->d_bits, (size_t)ntags * 14))) return rc;
-  if ((rc = ensure(c, c->d_ok, (size_t)ntags))) return rc;
-  if (ratio && (rc = ensure(c, c->d_ratio, (size_t)ntags * 112 * 4))) return rc;
-  // local positions of the tags inside in0 (demod.py:79: offset - nitems_written)
-  long long* loc = (long long*)malloc((size_t)ntags * 8);
-  if (!loc) return -ENOMEM;
+  // every buffer is acquired BEFORE anything is queued, so no error path leaves work in flight; all transfers go
+  // through the context's pinned scratch (layout: tag positions | packed bits | ok | ratios) and ONE synchronisation
+  const size_t nt = (size_t)ntags;
+  const size_t o_bits = nt * 8, o_ok = o_bits + nt * 14, o_ratio = (o_ok + nt + 15) & ~(size_t)15;
+  const size_t total = o_ratio + (ratio ? nt * 112 * sizeof(float) : 0);
+  int rc;
+  if ((rc = ensure_pinned(c, c->h_dm, c->h_dm_cap, total))) return rc;
+  if ((rc = ensure(c, c->d_tags, nt * 8))) return rc;
+  if ((rc = ensure(c, c->d_bits, nt * 14))) return rc;
+  if ((rc = ensure(c, c->d_ok, nt))) return rc;
+  if (ratio && (rc = ensure(c, c->d_ratio, nt * 112 * sizeof(float)))) return rc;
+  char* h = (char*)c->h_dm;
+  long long* loc = (long long*)h;
+  // local positions of the tags inside in0 (demod.py:79: offset - nitems_written); a tag outside the chunk -- the
+  // reference's get_tags_in_range never returns one (demod.py:67) -- is dropped by the kernel (ok = 0)
   for (int t = 0; t < ntags; ++t) loc[t] = tag_offsets[t] - nitems_read;
-  hipError_t he = hipMemcpyAsync(c->d_tags.p, loc, (size_t)ntags * 8, hipMemcpyHostToDevice, c->stream);
-  if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-  free(loc);
-  if (he != hipSuccess) return fail(c, -EIO, "tag upload", he);
-  int nb = (ntags + kWaves - 1) / kWaves;
-  if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL((k_slice<1>), dim3(nb), dim3(kThreads), 0, c->stream, (const void*)d, (long long)n,
-                     (const long long*)c->d_tags.p, (int)ntags, c->sps, (unsigned char*)c->d_bits.p,
-                     (unsigned char*)c->d_ok.p, ratio ? (float*)c->d_ratio.p : (float*)nullptr);
-  unsigned char* packed = (unsigned char*)malloc((size_t)ntags * 14);
-  if (!packed) return -ENOMEM;
-  he = hipMemcpyAsync(packed, c->d_bits.p, (size_t)ntags * 14, hipMemcpyDeviceToHost, c->stream);
-  if (he == hipSuccess) he = hipMemcpyAsync(ok, c->d_ok.p, (size_t)ntags, hipMemcpyDeviceToHost, c->stream);
-  if (he == hipSuccess && ratio) he = hipMemcpyAsync(ratio, c->d_ratio.p, (size_t)ntags * 112 * 4, hipMemcpyDeviceToHost, c->stream);
-  if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+  void* d = nullptr;
+  if ((rc = upload(c, in0, (size_t)n * 4, &d))) return rc;
+  hipError_t he = hipMemcpyAsync(c->d_tags.p, loc, nt * 8, hipMemcpyHostToDevice, c->stream);
+  if (he == hipSuccess) {
+    int nb = (ntags + kWaves - 1) / kWaves;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL((k_slice<1>), dim3(nb), dim3(kThreads), 0, c->stream, (const void*)d, (long long)n,
+                       (const long long*)c->d_tags.p, (int)ntags, c->sps, (unsigned char*)c->d_bits.p,
+                       (unsigned char*)c->d_ok.p, ratio ? (float*)c->d_ratio.p : (float*)nullptr);
+    he = hipMemcpyAsync(h + o_bits, c->d_bits.p, nt * 14, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (he == hipSuccess) he = hipMemcpyAsync(h + o_ok, c->d_ok.p, nt, hipMemcpyDeviceToHost, c->stream);
+  if (he == hipSuccess && ratio) he = hipMemcpyAsync(h + o_ratio, c->d_ratio.p, nt * 112 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+  const hipError_t hs = hipStreamSynchronize(c->stream);       // always: nothing stays queued behind an error return
+  if (he == hipSuccess) he = hs;
   if (he == hipSuccess) he = hipGetLastError();
-  if (he != hipSuccess) { free(packed); return fail(c, -EIO, "k_slice", he); }
-  for (int t = 0; t < ntags; ++t)
-    for (int k = 0; k < 112; ++k) bits112[(size_t)t * 112 + k] = (packed[(size_t)t * 14 + (k >> 3)] >> (7 - (k & 7))) & 1u;
-  free(packed);
+  if (he != hipSuccess) return fail(c, -EIO, "k_slice", he);
+  const unsigned char* packed = (const unsigned char*)(h + o_bits);
+  for (size_t t = 0; t < nt; ++t)
+    for (int k = 0; k < 112; ++k) bits112[t * 112 + k] = (packed[t * 14 + (k >> 3)] >> (7 - (k & 7))) & 1u;
+  memcpy(ok, h + o_ok, nt);
+  if (ratio) memcpy(ratio, h + o_ratio, nt * 112 * sizeof(float));
   return 0;
 }
 
-// Halo checks of a finished shard call (the records are in the slot's pinned buffer).
-static int shard_post(adsb_ctx* c, Slot& s, const Summary& sum, int32_t nres, bool drop_overlong) {
-  // a pulse still high at the end of the buffer was left out of the result (like framer.py:102-108 leaves out a
-  // pulse still high at the end of a call): an error for exact stitching, tolerated on request
+// Halo checks of a finished shard call (the records are in the slot's pinned buffer).  drop_overlong
+// (ADSB_SHARD_DROP_OVERLONG): a centre whose pulse or burst runs past the buffer's forward halo is left out of the
+// result instead of failing the call -- the reference degrades the same way (a pulse still high at the end of a
+// call is never evaluated, framer.py:102-108; a burst past the end of the chunk is dropped, demod.py:130-133).
+static int shard_post(adsb_ctx* c, Slot& s, const Summary& sum, int32_t* nres_io, bool drop_overlong) {
   if ((sum.flags & 4u) && !drop_overlong) return fail(c, -EOVERFLOW, "pulse runs past the shard's forward halo");
-  const Rec* r = (const Rec*)s.h_out;
+  Rec* r = (Rec*)s.h_out;
+  const int32_t nres = *nres_io;
   const long long origin = s.plan.origin, n = s.plan.n, stream_len = s.plan.origin + s.plan.dem_hi;
+  int32_t w = 0;
   for (int i = 0; i < nres; ++i) {
     const unsigned fl = (unsigned)(r[i].w[3] >> 48);
     const long long off = (long long)r[i].w[0];
     const long long eob = off + 119ll * c->sps + c->sps / 2;
     if (!(fl & kDemod) && eob < stream_len) return fail(c, -EOVERFLOW, "internal: demod flag");
-    if ((fl & kDemod) && eob >= origin + n) return fail(c, -EOVERFLOW, "burst runs past the shard's forward halo");
+    if ((fl & kDemod) && eob >= origin + n) {
+      if (drop_overlong) continue;
+      return fail(c, -EOVERFLOW, "burst runs past the shard's forward halo");
+    }
     if (off - 100 < origin && origin > 0) return fail(c, -EOVERFLOW, "noise window runs past the shard's back halo");
+    if (w != i) r[w] = r[i];
+    ++w;
   }
+  s.nres = w;
+  *nres_io = w;
   return 0;
 }
 
@@ -744,7 +836,7 @@ int adsb_shard_device(adsb_ctx* c, int fmt, const void* d_data, int64_t n, int64
   int32_t nres = 0;
   rc = run_pipeline(c, pl, &s, &nres);
   if (rc) return rc;
-  if ((rc = shard_post(c, c->slot[c->last_slot], s, nres))) return rc;
+  if ((rc = shard_post(c, c->slot[c->last_slot], s, &nres))) return rc;
   return deliver(c, nres, out, cap, n_out);
 }
 
@@ -761,7 +853,7 @@ int adsb_shard_host(adsb_ctx* c, int fmt, const void* host, int64_t n, int64_t o
   Summary s;
   int32_t nres = 0;
   if ((rc = run_pipeline(c, pl, &s, &nres))) return rc;
-  if ((rc = shard_post(c, c->slot[c->last_slot], s, nres, (shard_flags & ADSB_SHARD_DROP_OVERLONG) != 0))) return rc;
+  if ((rc = shard_post(c, c->slot[c->last_slot], s, &nres, (shard_flags & ADSB_SHARD_DROP_OVERLONG) != 0))) return rc;
   return deliver(c, nres, out, cap, n_out);
 }
 

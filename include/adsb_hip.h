@@ -13,6 +13,8 @@
  *                                   examples/adsb_rx.py:180-196 (one canonical work() call per block)
  *   adsb_process_mag2[_device]      the same chain from the framer's float input onwards
  *   adsb_submit_*_device / adsb_wait   the same, up to ADSB_MAX_IN_FLIGHT calls in flight (no reference counterpart: pipelining)
+ *   adsb_submit_format_host         the same fed from host memory: the SDR source -> framer chain of examples/adsb_rx.py:113-126,180-196
+ *   adsb_last_confidence            demod.bit_confidence           python/adsb/demod.py:97-101
  *   adsb_shard_device / adsb_shard_fixup / adsb_stitch   (no reference counterpart: overlapped time shards, host stitch)
  *
  * Conventions: the caller owns every buffer it passes; the library owns device memory, pinned staging
@@ -31,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ADSB_ABI_VERSION 1
+#define ADSB_ABI_VERSION 2
 #ifndef ADSB_MAX_IN_FLIGHT
 #define ADSB_MAX_IN_FLIGHT 3 /* adsb_submit_* calls that may be pending at once */
 #endif
@@ -56,6 +58,13 @@ extern "C" {
  * emulation) ignores it.  Records of such a context carry ADSB_BURST_LONG_HINT, which adsb_shard_fixup / adsb_stitch
  * honour. */
 #define ADSB_FLAG_LONG_AWARE_GATE 2u
+/* Opt-in: keep what demod.work() keeps as self.bit_confidence (demod.py:97-101, never published by the reference) for
+ * every delivered burst of the whole-buffer entry points -- the float32 ratios bit1_amp / bit0_amp, see
+ * adsb_last_confidence.  Costs one extra small kernel and copy per call. */
+#define ADSB_FLAG_CONFIDENCE 4u
+/* Run the sparse tail of a pass on the compute stream behind its k_detect instead of on a second stream beside the
+ * next pass's k_detect (profiling aid: serial kernels; about 15 % less throughput with several calls in flight). */
+#define ADSB_FLAG_SINGLE_STREAM 8u
 
 /* adsb_burst.flags */
 #define ADSB_BURST_DEMOD 1u /* eob inside the demod input: bits[] valid, a PDU is published (demod.py:82) */
@@ -153,6 +162,11 @@ int adsb_process_format(adsb_ctx* ctx, int format, const void* host, int64_t n, 
 int adsb_process_format_device(adsb_ctx* ctx, int format, const void* d_data, int64_t n, int64_t abs_offset,
                                adsb_burst* out, int32_t cap, int32_t* n_out);
 int adsb_last_result(adsb_ctx* ctx, const adsb_burst** bursts, int32_t* n);
+/* ADSB_FLAG_CONFIDENCE contexts: *ratio -> n x 112 float32 in the context's pinned memory, row t = bit1_amp / bit0_amp
+ * of burst t of the last finished call (demod.py:91-101: 10*log10 of it is bit_confidence; +-inf / NaN where the
+ * reference has them); rows of bursts without ADSB_BURST_DEMOD are zero.  Valid until the same pipeline slot is
+ * used again.  -EINVAL on a context created without the flag. */
+int adsb_last_confidence(adsb_ctx* ctx, const float** ratio, int32_t* n);
 
 /* Asynchronous form of adsb_process_*_device: submit queues the whole device pipeline on the context's
  * streams and returns a ticket (0 .. ADSB_MAX_IN_FLIGHT-1) at once; adsb_wait blocks for that call, copies
@@ -165,6 +179,13 @@ int adsb_submit_iq_device(adsb_ctx* ctx, const void* d_iq, int64_t n, int64_t ab
 int adsb_submit_mag2_device(adsb_ctx* ctx, const void* d_mag2, int64_t n, int64_t abs_offset, int32_t* ticket);
 int adsb_submit_iq16_device(adsb_ctx* ctx, const void* d_iq16, int64_t n, int64_t abs_offset, int32_t* ticket);
 int adsb_submit_format_device(adsb_ctx* ctx, int format, const void* d_data, int64_t n, int64_t abs_offset, int32_t* ticket);
+/* Host-fed streaming, the topology of examples/adsb_rx.py:113-126,180-196 (SDR source -> ... -> framer -> demod) with
+ * the chunks in host memory: the samples are uploaded on a dedicated stream into the ticket's own device buffer, so
+ * with several calls in flight the upload of chunk i+1 runs beside the kernels of chunk i and the record download of
+ * chunk i-1 (PCIe both ways, compute in between).  A page-locked source (adsb_host_alloc) is DMA'd where it lies and
+ * must stay valid until adsb_wait returns; a pageable source is copied through pinned chunks before the call returns
+ * (the call then takes as long as that copy).  Results exactly as adsb_process_format. */
+int adsb_submit_format_host(adsb_ctx* ctx, int format, const void* host, int64_t n, int64_t abs_offset, int32_t* ticket);
 int adsb_submit_shard_device(adsb_ctx* ctx, int fmt, const void* d_data, int64_t n, int64_t origin, int64_t own_lo,
                              int64_t own_hi, int64_t stream_len, int32_t head_cands, int32_t* ticket);
 int adsb_wait(adsb_ctx* ctx, int32_t ticket, adsb_burst* out, int32_t cap, int32_t* n_out);

@@ -194,6 +194,7 @@ inline void adsb_wave_sync() {
 }
 
 inline int adsb_uniform(int v) { return v; }
+inline int adsb_opaque(int v) { return v; }
 inline int adsb_readlane(int v, int lane) { return hipsim_shfl_idx(v, lane); }
 inline unsigned long long adsb_bitrep32(unsigned x) {
   unsigned long long r = 0;

@@ -19,6 +19,7 @@ struct SimOut {
   long long lastp, last_kept;
 };
 
+static float* g_conf_out = nullptr; // sim_set_confidence_out: [n_kept][112] ratios of the next run (k_confidence), or null
 static int g_long_aware = 0;      // opt-in length-aware gate (ADSB_FLAG_LONG_AWARE_GATE): set by sim_set_long_aware
 
 #define SIM_BY_MODE(mode, K, ...)                          \
@@ -57,8 +58,8 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   float* dbuf = (float*)aligned_alloc(64, ((nby + 63) / 64 + 1) * 64);
   memcpy(dbuf, data, nby);
 
-  std::vector<unsigned long long> cands(tot), sorted(tot), kept(tot);
-  std::vector<Rec> outv(tot);
+  std::vector<unsigned long long> cands(tot), sorted(tot);
+  std::vector<Rec> recs(tot), sorted_recs(tot), outv(tot);
   std::vector<int> blk_count(nlists), blk_off(nlists), seg(tot / kThreads + 2);
   std::vector<long long> blk_lastp(nlists);
   std::vector<unsigned> blk_flags(nlists);
@@ -72,7 +73,7 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   a.dem_hi = dem_hi; a.origin = origin; a.chunk = chunk; a.thr = thr; a.prev_in0 = prev_in0; a.scale = scale; a.sps = sps;
   a.long_aware = g_long_aware;
   a.end_is_call_end = end_is_call_end; a.rec_cap = rec_cap; a.long_cap = (int)(ntiles + 1);
-  a.cands = cands.data(); a.blk_count = blk_count.data(); a.blk_lastp = blk_lastp.data();
+  a.cands = cands.data(); a.recs = recs.data(); a.blk_count = blk_count.data(); a.blk_lastp = blk_lastp.data();
   a.blk_flags = blk_flags.data(); a.longlist = longlist.data(); a.long_count = &long_count;
   a.long_lastp = &long_lastp;
 
@@ -82,8 +83,8 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     hipsim::launch(k_scan, 1, kThreads, (const int*)blk_count.data(), (const long long*)blk_lastp.data(),
                    (const unsigned*)blk_flags.data(), nlists, rec_cap, (const int*)&long_count,
                    (const unsigned long long*)&long_lastp, blk_off.data(), &sum);
-    hipsim::launch(k_gather, nlists < 8 ? nlists : 8, kThreads, (const unsigned long long*)cands.data(),
-                   (const int*)blk_count.data(), (const int*)blk_off.data(), nlists, rec_cap, sorted.data());
+    hipsim::launch(k_gather, nlists < 8 ? nlists : 8, kThreads, (const unsigned long long*)cands.data(), (const Rec*)recs.data(),
+                   (const int*)blk_count.data(), (const int*)blk_off.data(), nlists, rec_cap, sorted.data(), sorted_recs.data());
     unsigned fmask = 0u, fwant = 0u;
     if (gate) {
       hipsim::launch(k_resolve, 3, kThreads, sorted.data(), (const Summary*)&sum, (long long)63 * sps,
@@ -92,9 +93,9 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     }
     hipsim::launch(k_count, 3, kThreads, (const unsigned long long*)sorted.data(), (const Summary*)&sum, fmask, fwant,
                    head_n, seg.data());
-    hipsim::launch(k_compact, 3, kThreads, (const unsigned long long*)sorted.data(), &sum, (const int*)seg.data(),
-                   fmask, fwant, head_n, kept.data(), (int)tot, &long_count, &long_lastp);
-    SIM_BY_MODE(mode, k_burst, 2, kThreads, a, (const unsigned long long*)kept.data(), (const Summary*)&sum, outv.data(), (int)tot, (Summary*)nullptr);
+    hipsim::launch(k_compact, 3, kThreads, (const unsigned long long*)sorted.data(), (const Rec*)sorted_recs.data(), &sum,
+                   (const int*)seg.data(), fmask, fwant, head_n, outv.data(), (int)tot, &long_count, &long_lastp);
+    if (g_conf_out) SIM_BY_MODE(mode, k_confidence, 2, kThreads, a, (const Rec*)outv.data(), (const Summary*)&sum, (int)tot, g_conf_out);
   }
   so->n_rec = sum.n_rec; so->n_kept = sum.n_kept; so->overflow = sum.overflow; so->long_count = sum.long_count;
   so->flags = sum.flags; so->lastp = sum.lastp; so->last_kept = sum.last_kept_p;
@@ -107,6 +108,7 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
 }
 
 void sim_set_long_aware(int v) { g_long_aware = v; }
+void sim_set_confidence_out(float* p) { g_conf_out = p; }
 
 // --- the library's three call shapes, through the same adsb_plan.h the library uses ------------------
 int sim_canonical(int mode, const float* data, long long n, long long abs_offset, float thr, int sps, int grid_max,

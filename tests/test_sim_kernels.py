@@ -210,6 +210,13 @@ def test_replay_blocks_equal_one_canonical_call(bps, block, head, growth, monkey
     from gr_adsb_amd import replay
     fs, sps, n = 2e6, 2, (1 << 16) + 777
     iq = M.synth_iq(n, fs, bps, seed=19)
+    if head == 1:
+        # an unbroken chain across every block boundary: clean preambles every 100 samples (< the 126-sample gate), so
+        # every other one is kept and a 1-centre head region cannot re-synchronise -> greedy fallback
+        x = np.full(n, 1e-4, dtype=np.float32)
+        for base in range(50, n - 400, 100):
+            x[base + np.array([0, 2, 7, 9])] = 1.0
+        iq = np.sqrt(x).astype(np.complex64)
 
     def shard_fn(plan, head_cands):
         return simlib.sim_shard(0, iq[plan["lo"]:plan["hi"]], plan["lo"], plan["own_lo"], plan["own_hi"], n, fs, 0.01,

@@ -30,6 +30,19 @@ __device__ __forceinline__ int adsb_opaque(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
+// streamed single-use data: non-temporal load (ADSB_NT_LOADS=0 in a tuning build restores the default cache policy)
+#ifndef ADSB_NT_LOADS
+#define ADSB_NT_LOADS 1
+#endif
+template <class Q>
+__device__ __forceinline__ Q adsb_ld_stream(const char* p) {
+#if ADSB_NT_LOADS
+  using V = float __attribute__((ext_vector_type(sizeof(Q) / 4)));
+  return __builtin_bit_cast(Q, __builtin_nontemporal_load(reinterpret_cast<const V*>(p)));
+#else
+  return *reinterpret_cast<const Q*>(p);
+#endif
+}
 // bit i of x -> bits 2i and 2i+1 (scalar unit; the argument must be wave-uniform)
 __device__ __forceinline__ unsigned long long adsb_bitrep32(unsigned x) {
   unsigned long long r;
@@ -745,8 +758,8 @@ int adsb_demod_work(adsb_ctx* c, const float* in0, int64_t n, int64_t nitems_rea
                     int32_t ntags, uint8_t* bits112, uint8_t* ok, float* ratio) {
   if (!c || n < 0 || ntags < 0 || (n > 0 && !in0) || (ntags > 0 && (!tag_offsets || !bits112 || !ok))) return -EINVAL;
   if (ntags == 0) return 0;
-  for (const Slot& sl : c->slot) if (sl.busy) return fail(c, -EBUSY, "a submitted call is still pending (adsb_wait first)");
   HIPCHK(c, hipSetDevice(c->device));
+  // (independent of submitted calls still in flight: own buffers, ordered behind them on the compute stream)
   // every buffer is acquired BEFORE anything is queued, so no error path leaves work in flight; all transfers go
   // through the context's pinned scratch (layout: tag positions | packed bits | ok | ratios) and ONE synchronisation
   const size_t nt = (size_t)ntags;

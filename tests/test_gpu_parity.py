@@ -105,6 +105,9 @@ def test_dropin_blocks_match_reference_goldens(native, name, sched):
     dm = blocks.demod(g.fs)
     dm.start_timestamp = 0.0
     assert fr.name() == "ADS-B Framer" and dm.name() == "demod" and fr.history() == 8 * g.sps
+    confs = []                                   # demod.bit_confidence as it stands when each PDU is published
+    pub = dm.message_port_pub
+    dm.message_port_pub = lambda port, msg: (confs.append(np.array(dm.bit_confidence, dtype=np.float32)), pub(port, msg))[1]
     tags, msgs = grshim.drive(fr, dm, g.x, None if sched == "single" else g.sched(sched))
     assert np.array_equal(np.array([t.offset for t in tags], dtype=np.int64), g.get(sched, "tag_offsets"))
     assert all(t.key == "burst" and t.srcid == "framer" and t.value[0] == "SOB" for t in tags)
@@ -118,6 +121,13 @@ def test_dropin_blocks_match_reference_goldens(native, name, sched):
     psnr = np.array([m[0]["snr"] for _, m in msgs], dtype=np.float32)
     assert np.array_equal(psnr.view(np.uint32), g.get(sched, "pdu_snr_bits"))
     assert all(set(m[0].keys()) == {"timestamp", "snr"} and m[1].dtype == np.uint8 and len(m[1]) == 112 for _, m in msgs)
+    # demod.py:101: a PDU's confidence depends on its own samples only, so under any schedule it equals the row the
+    # reference produced for the same burst in its single call (the goldens store those)
+    single = dict(zip(g.get("single", "pdu_offsets").tolist(), g.get("single", "pdu_conf_bits")))
+    assert len(confs) == len(offs)
+    for o, cf in zip(offs.tolist(), confs):
+        if o in single:
+            assert np.array_equal(cf.view(np.uint32), single[o])
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -211,16 +221,54 @@ def test_long_aware_gate(native, torch_mod, fs, bps):
         blocks.framer(fs, 0.01, long_aware=True)
 
 
-def test_demod_confidence_bits(native):
-    g = Golden("g2msps_df17")
+@pytest.mark.parametrize("name", golden_names())
+def test_demod_confidence_bits(native, name):
+    """demod.py:97-101 on every golden (2/4/8/20 Msps, the low-SNR DF mix included): the stand-alone demod entry
+    returns the exact float32 ratios; 10*log10 of them is the reference's bit_confidence, bit for bit."""
+    g = Golden(name)
     ctx = native.Context(g.fs, g.thr)
     offs = g.get("single", "pdu_offsets")
     bits, ok, ratio = ctx.demod_work(g.x, 0, offs, want_ratio=True)
-    assert ok.all()
+    assert ok.all() and len(offs) > 10
     assert np.array_equal(bits, g.pdu_bits("single"))
-    with np.errstate(all="ignore"):
-        conf = (np.float32(10.0) * np.log10(ratio)).astype(np.float32)
-    assert np.array_equal(conf.view(np.uint32), g.get("single", "pdu_conf_bits"))
+    assert np.array_equal(native.confidence_db(ratio).view(np.uint32), g.get("single", "pdu_conf_bits"))
+    # a tag in front of the chunk (the reference's get_tags_in_range never hands one over, demod.py:67) is dropped
+    bits2, ok2, _ = ctx.demod_work(g.x[1000:], 1000, np.concatenate([[1000 - 8 * g.sps - 1], offs[offs >= 1000]]))
+    assert not ok2[0] and ok2[1:].all() and np.array_equal(bits2[1:], g.pdu_bits("single")[offs >= 1000])
+
+
+@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("entry", ["iq", "mag2", "iq16"])
+def test_fused_path_confidence(native, name, entry):
+    """ADSB_FLAG_CONFIDENCE: the whole-buffer (fused) path returns the same ratios for every burst it delivers a PDU
+    for -- SURVEY §8b-B3's optional conf_ratio[112] -- checked against the reference's bit_confidence bits."""
+    g = Golden(name)
+    ctx = native.Context(g.fs, g.thr, flags=native.FLAG_CONFIDENCE)
+    if entry == "iq":
+        recs = ctx.process_iq(g.iq)
+    elif entry == "mag2":
+        recs = ctx.process_mag2(g.x)
+    else:
+        ctx.set_iq16_scale(2.0 / 32767.0)
+        recs = ctx.process_iq16(g.z["iq16"])
+    assert_recs_match_golden(recs, g)
+    ratio = ctx.last_confidence()
+    assert ratio.shape == (len(recs), 112)
+    dem = (recs["flags"] & 1) != 0
+    assert np.array_equal(native.confidence_db(ratio[dem]).view(np.uint32), g.get("single", "pdu_conf_bits"))
+    assert not np.any(ratio[~dem].view(np.uint32))                     # rows without a PDU stay zero
+    # pipelined form: the ratios follow the ticket
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(g.x)).to("cuda:0")
+    tk = [ctx.submit_mag2_device(t.data_ptr(), len(g.x)) for _ in range(2)]
+    for k in tk:
+        r2 = ctx.wait(k)
+        assert np.array_equal(r2["offset"], recs["offset"])
+        assert np.array_equal(ctx.last_confidence().view(np.uint32), ratio.view(np.uint32))
+    plain = native.Context(g.fs, g.thr)
+    plain.process_mag2(g.x)
+    with pytest.raises(native.AdsbError):
+        plain.last_confidence()
 
 
 def test_set_threshold_takes_effect_next_call(native):
@@ -665,6 +713,74 @@ def test_adversarial_streams(native):
         assert_recs_equal(ctx.process_mag2(x), want, "seed %d" % seed)
         checked += len(want)
     assert checked > 100
+
+
+def test_host_fed_pipeline_equals_blocking_calls(native):
+    """adsb_submit_format_host: chunks in host memory (page-locked: DMA'd where they lie; pageable: through the
+    pinned chunk ring, > 16 MiB so that the ring wraps), three in flight, == the blocking entry points == the oracle."""
+    from gr_adsb_amd import modulator as M
+    from oracle import adsb_oracle as O
+    from oracle import c_oracle as C
+    fs, n = 2e6, (1 << 22) + 12345
+    chunks = [M.synth_iq(n, fs, 3000, seed=70 + k) for k in range(4)]
+    want = [C.canonical(O.mag2(c), 2, np.float32(0.01)) for c in chunks]
+    ctx = native.Context(fs, 0.01)
+    pins = []
+    for c in chunks:
+        pa = native.PinnedArray(n, np.complex64)
+        pa.array[:] = c
+        pins.append(pa)
+    for src in ([p.array for p in pins], chunks):            # pinned, then pageable
+        pending, got = [], []
+        for k in range(8):
+            pending.append((k % 4, ctx.submit_format_host(native.FMT_FC32, src[k % 4], abs_offset=k * 1000)))
+            if len(pending) == native.MAX_IN_FLIGHT:
+                j, t = pending.pop(0)
+                got.append((j, len(got) * 1000, ctx.wait(t)))
+        while pending:
+            j, t = pending.pop(0)
+            got.append((j, len(got) * 1000, ctx.wait(t)))
+        assert len(got) == 8
+        for j, off, recs in got:
+            r = recs.copy()
+            r["offset"] -= off
+            assert_recs_equal(r, want[j], "host-fed chunk %d" % j)
+    # int16 chunks through the same entry (4 B/sample)
+    q = M.quantize_iq16(chunks[0])
+    ctx.set_iq16_scale(2.0 / 32767.0)
+    t = ctx.submit_format_host(native.FMT_SC16, q)
+    assert_recs_equal(ctx.wait(t), ctx.process_iq16(q), "host-fed int16")
+    with pytest.raises(native.AdsbError):
+        for _ in range(native.MAX_IN_FLIGHT + 1):
+            ctx.submit_format_host(native.FMT_FC32, chunks[0])
+    ctx.close()
+
+
+@pytest.mark.parametrize("n", [6000, 6600])        # pulse inside k_detect's LDS window / longer than it (k_longrun)
+def test_shard_host_drop_overlong_never_raises(native, n):
+    """with ADSB_SHARD_DROP_OVERLONG a matched centre whose burst runs past the buffer is left out
+    (the reference degrades, it never raises: framer.py:102-108, demod.py:130-133); without the flag it is an error."""
+    from oracle import c_oracle as C
+    sps, fs = 8, 8e6
+    x = np.full(n, 1e-4, dtype=np.float32)
+    # a pulse 600 samples long (longer than k_detect's 256-sample window: k_longrun) whose centre matches the
+    # preamble template: plateau just above the threshold, spikes where chips 0, 2, 7, 9 are sampled (stride sps/2)
+    r = n - 700
+    x[r:r + 600] = 0.02
+    p = (r + r + 600) // 2
+    x[p + np.array([0, 2, 7, 9]) * (sps // 2)] = 1.0
+    ctx = native.Context(fs, 0.01)
+    kept = ctx.shard_host(native.FMT_MAG2, x, 0, 0, n - 64, native.STREAM_UNBOUNDED, head_cands=64, drop_overlong=True)
+    assert p not in kept["offset"].tolist()
+    with pytest.raises(native.AdsbError) as ei:
+        ctx.shard_host(native.FMT_MAG2, x, 0, 0, n - 64, native.STREAM_UNBOUNDED, head_cands=64, drop_overlong=False)
+    assert ei.value.code == -75
+    # the same centre with room behind it is an ordinary record
+    x2 = np.concatenate([x, np.full(2000, 1e-4, dtype=np.float32)])
+    kept2 = ctx.shard_host(native.FMT_MAG2, x2, 0, 0, len(x2) - 64, native.STREAM_UNBOUNDED, head_cands=64, drop_overlong=True)
+    assert p in kept2["offset"].tolist()
+    want = C.canonical(x2, sps, np.float32(0.01))
+    assert_recs_equal(kept2[kept2["offset"] == p], want[want["offset"] == p], "long-pulse record")
 
 
 def test_c_abi_output_array_and_error_paths(native):

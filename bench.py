@@ -5,8 +5,16 @@ A step = one pass of the hot path (|IQ|^2 -> preamble detect/tag -> gate -> PPM 
 back in pinned host memory) over one batch of synthetic complex64 IQ that is already resident in HBM.
 N=1 workload: BASELINE.json configs[1] -- synthetic 2 Msps IQ, ~1k DF17 bursts/s.  With N>1 each rank
 owns one overlapped time shard of an N-times longer stream (weak scaling): it detects and gates its own
-shard, the ranks exchange only their 8-byte end-of-burst tail state, and each fixes up the head of its
+shard, the ranks exchange only their 16-byte end-of-burst state, and each fixes up the head of its
 shard on the host (no data-path collective).
+
+The timed region is EXACTLY K steps between barrier + synchronize on both sides, max over ranks; it is
+repeated until at least --min-time seconds have been timed (never fewer than 3 repeats) and the MEDIAN
+repeat is reported (`timing` holds min / median / max).
+
+One JSON line.  Beside the headline it carries (N=1): `roofline`, `cpu_baseline` (four CPU legs timed on
+this box's host cores in the same run), `bit_match`, `host_fed` (PCIe-inclusive rates of the host-fed entry
+point next to a plain pinned H2D copy) and `extra_configs` (BASELINE configs 3, 4, 5 at 2^28 samples).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--fs 2e6] [--log2n 30] [--bursts 1000]
 """
@@ -22,9 +30,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# environment variables the bench knows about; any other ADSB_* variable is refused (a stray tuning knob must never
+# produce an unlabelled number), the known ones are recorded in config.env
+KNOWN_ENV = ("ADSB_BENCH_ONE_GPU", "ADSB_SHARD_EXCHANGE", "ADSB_HIP_LIB")
+DF_MIX = ((11, 0, 4, 17, 20, 5, 21), (2335, 1395, 732, 582, 61, 34, 32))   # reference docs/DF_histogram.txt:4-21
 
 
-def gen_stream_blocks(n_local, origin, fs, bursts_per_s, seed, device, block=1 << 22):
+def gen_stream_blocks(n_local, origin, fs, bursts_per_s, seed, device, block=1 << 22, **synth):
     """Deterministic stream: block b (block samples) depends only on (seed, b), so overlapping shards
     generated on different ranks hold identical samples where they overlap."""
     import torch
@@ -33,7 +45,7 @@ def gen_stream_blocks(n_local, origin, fs, bursts_per_s, seed, device, block=1 <
     b1 = (origin + n_local + block - 1) // block
     parts = []
     for b in range(b0, b1):
-        parts.append(M.synth_iq_torch(block, fs, bursts_per_s, seed * 1000003 + b, device))
+        parts.append(M.synth_iq_torch(block, fs, bursts_per_s, seed * 1000003 + b, device, **synth))
     full = torch.cat(parts, dim=0) if len(parts) > 1 else parts[0]
     s = origin - b0 * block
     out = full[s:s + n_local].contiguous()
@@ -48,18 +60,18 @@ def pmc_traffic(fs, log2n, bursts):
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             for e in json.load(f)["entries"]:
                 if e["fs"] == fs and e["log2n"] == log2n and e["bursts"] == bursts:
-                    return int(e["traffic_bytes"])
+                    return int(e["traffic_bytes"]), e.get("source")
     except (OSError, ValueError, KeyError):
         pass
-    return None
+    return None, None
 
 
-def cpu_baseline(iq_host, sps, thr, reps=5):
-    """Single-core C port of the reference path (oracle/adsb_oracle.c) on a bounded sample."""
+# ---- CPU baselines (oracle/: test infrastructure, used here only as the thing timed beside the GPU) -------------
+def cpu_c_port(iq_host, sps, thr, reps=3):
+    """Single-core scalar C port of the reference path (oracle/adsb_oracle.c) on a bounded sample."""
     from oracle import c_oracle as C
     C.lib()
-    best = None
-    recs = None
+    best, recs = None, None
     for _ in range(reps):
         t0 = time.perf_counter()
         recs = C.process_iq(iq_host, sps, thr)
@@ -68,19 +80,288 @@ def cpu_baseline(iq_host, sps, thr, reps=5):
     return len(iq_host) / best / 1e6, recs
 
 
-def cpu_baseline_threads(iq_host, sps, thr, threads):
+def cpu_c_port_threads(iq_host, sps, thr, threads):
     """The same C port on `threads` host threads, one contiguous shard each (ctypes releases the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import c_oracle as C
-    n = len(iq_host)
-    per = n // threads
+    per = len(iq_host) // threads
     shards = [iq_host[i * per:(i + 1) * per] for i in range(threads)]
     with ThreadPoolExecutor(max_workers=threads) as ex:
-        list(ex.map(lambda s_: C.process_iq(s_, sps, thr), shards[:threads]))        # warm
+        list(ex.map(lambda s_: C.process_iq(s_, sps, thr), shards))        # warm
         t0 = time.perf_counter()
         list(ex.map(lambda s_: C.process_iq(s_, sps, thr), shards))
         dt = time.perf_counter() - t0
     return per * threads / dt / 1e6
+
+
+def cpu_reference_structured(x, fs, thr, procs):
+    """oracle/ref_structured.py -- vectorised front end + per-pulse Python loop + np.median, the reference's own cost
+    structure -- on one core, and on `procs` processes as overlapped time shards + stitch."""
+    import multiprocessing as mp
+    from oracle import ref_structured as RS
+    n1 = min(len(x), 1 << 23)
+    stats = {}
+    t0 = time.perf_counter()
+    one = RS.run_stream(x[:n1], fs, thr, stats=stats)
+    t1 = time.perf_counter() - t0
+    out = {"one_core": {"value": round(n1 / t1 / 1e6, 2), "unit": "Msamples/s", "cores": 1,
+                        "sample": "first 2^%d samples, %d pulses of which %d evaluated, %d tags" % (
+                            int(np.log2(n1)), stats.get("pulses", 0), stats.get("evaluated", 0), len(one["tag_offsets"]))}}
+    if procs > 1:
+        from concurrent.futures import ProcessPoolExecutor
+        try:
+            # spawn, never fork: the parent holds a HIP context.  Every wait is bounded: a worker that cannot start must
+            # cost the bench one record, not the run.
+            with ProcessPoolExecutor(max_workers=procs, mp_context=mp.get_context("spawn")) as ex:
+                list(ex.map(abs, range(procs), timeout=180))   # workers up (interpreter + numpy import) before the clock starts
+                t0 = time.perf_counter()
+                sh = RS.run_sharded(x, fs, thr, procs, pool_map=lambda f, jobs: ex.map(f, jobs, timeout=600))
+                tp = time.perf_counter() - t0
+            cut = n1 - 200 * int(fs // 1e6)
+            ok = bool(np.array_equal(sh["tag_offsets"][sh["tag_offsets"] < cut], one["tag_offsets"][one["tag_offsets"] < cut]))
+            out["all_cores"] = {"value": round(len(x) / tp / 1e6, 2), "unit": "Msamples/s", "processes": procs,
+                                "sample": "first 2^%d samples as %d overlapped time shards (one process each, warm-up "
+                                          "%d samples, host stitch), %d tags; shard pickling included" % (
+                                              int(np.log2(len(x))), procs, RS.WARM, len(sh["tag_offsets"])),
+                                "agrees_with_one_core_leg": ok, "serial_fallback": bool(sh["fallback"])}
+        except Exception as e:                                   # noqa: BLE001
+            out["all_cores"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+def recs_match(a, b):
+    return bool(len(a) == len(b) and np.array_equal(a["offset"], b["offset"]) and np.array_equal(a["bits"], b["bits"])
+                and np.array_equal(a["median"].view(np.uint32), b["median"].view(np.uint32))
+                and np.array_equal(a["peak"].view(np.uint32), b["peak"].view(np.uint32))
+                and np.array_equal(a["flags"] & 1, b["flags"] & 1))
+
+
+def timed_repeats(step, drain, sync_all, reduce_max, steps, min_time, max_repeats=400):
+    """EXACTLY `steps` steps per repeat, bracketed by sync_all (barrier + synchronize); repeats until min_time seconds
+    have been timed.  Every rank sees the same reduced times, so every rank stops at the same repeat."""
+    times, nb = [], 0
+    while True:
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        nb = drain()
+        sync_all()
+        times.append(reduce_max(time.perf_counter() - t0))
+        if (len(times) >= 3 and sum(times) >= min_time) or len(times) >= max_repeats:
+            return times, nb
+
+
+def roofline_of(st, fmt_name, iso_ms=None):
+    kern_ms = st["detect_ms"] / max(1, st["detect_launches"])
+    alg = st["detect_bytes"] / max(1, st["detect_launches"])
+    ach = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    r = {"bound": "hbm", "kernel": "k_detect<%s>" % fmt_name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(ach / HBM_PEAK_GBS, 4), "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(alg),
+         "launches_timed": int(st["detect_launches"])}
+    if iso_ms:
+        r["isolated"] = {"kernel_ms": round(iso_ms, 4), "achieved": round(alg / (iso_ms * 1e-3) / 1e9, 1),
+                         "frac": round(alg / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "same kernel, blocking passes, nothing else on the GPU"}
+    return r
+
+
+def run_single_gpu_config(fe, fmt, iq, n, steps, warmup, min_time, depth):
+    """Pipelined canonical passes over a resident buffer; returns (median ms/step, times, stats, bursts, iso_ms)."""
+    for _ in range(2):
+        fe.ctx.process_format_device(fmt, iq.data_ptr(), n, 0, fetch=False)
+    fe.ctx.reset_stats()
+    for _ in range(4):
+        fe.ctx.process_format_device(fmt, iq.data_ptr(), n, 0, fetch=False)
+    s0 = fe.stats()
+    iso_ms = s0["detect_ms"] / max(1, s0["detect_launches"])
+    import torch
+    pending = []
+
+    def step():
+        pending.append(fe.submit_format_tensor(fmt, iq, 0))
+        if len(pending) == depth:
+            fe.wait(pending.pop(0), fetch=False)
+
+    def drain():
+        nb = 0
+        while pending:
+            nb = fe.wait(pending.pop(0), fetch=False)
+        return nb
+
+    for _ in range(warmup):
+        step()
+    drain()
+    fe.ctx.reset_stats()
+    times, nb = timed_repeats(step, drain, torch.cuda.synchronize, lambda t: t, steps, min_time)
+    return float(np.median(times)) / steps * 1e3, times, fe.stats(), nb, iso_ms
+
+
+def sharded_on_one_gpu(fe, iq, n, sps, shards, depth):
+    """BASELINE config 4's decomposition on ONE GPU: the resident stream as `shards` overlapped time shards, each
+    detected and gated on the device as a fresh stream, heads re-gated on the host with the carried end-of-burst
+    state (the multi-GPU stitch run sequentially).  Returns (records of the whole stream, callable running one step)."""
+    from gr_adsb_amd import _native, replay
+    from gr_adsb_amd.frontend import shard_plan
+    plans = [p for p in shard_plan(n, shards, sps) if p["own_hi"] > p["own_lo"]]
+
+    def one_step(collect):
+        eob, pending, out = _native.EOB_NONE, [], []
+
+        def finish(p, t):
+            nonlocal eob
+            recs = fe.wait(t, copy=False)
+            kept = _native.shard_fixup(recs, sps, eob, inplace=True)
+            if kept is None:                              # head region ends inside a chain: ungated list + greedy gate
+                stash = [(q, fe.wait(u)) for q, u in pending]
+                pending.clear()
+                kept = replay.greedy_gate(fe.shard_tensor(iq[p["lo"]:p["hi"]], p["lo"], p["own_lo"], p["own_hi"], n), sps, eob)
+                if len(kept):
+                    eob = int(kept["offset"][-1]) + int(_native.gate_window(kept[-1:], sps)[0])
+                if collect:
+                    out.append(kept.copy())
+                for q, r in stash:
+                    k2 = _native.shard_fixup(r, sps, eob)
+                    assert k2 is not None, "bench: consecutive unsynchronised shards"
+                    if len(k2):
+                        eob = int(k2["offset"][-1]) + int(_native.gate_window(k2[-1:], sps)[0])
+                    if collect:
+                        out.append(k2)
+                return
+            if len(kept):
+                eob = int(kept["offset"][-1]) + int(_native.gate_window(kept[-1:], sps)[0])
+            if collect:
+                out.append(kept.copy())
+
+        for p in plans:
+            pending.append((p, fe.submit_shard_tensor(iq[p["lo"]:p["hi"]], p["lo"], p["own_lo"], p["own_hi"], n,
+                                                      head_cands=64)))
+            if len(pending) == depth:
+                finish(*pending.pop(0))
+        while pending:
+            finish(*pending.pop(0))
+        return np.concatenate(out) if collect and out else None
+
+    return one_step
+
+
+def extra_configs(args, dev, depth):
+    """BASELINE configs 3, 4 and 5 after the headline leg, each on 2^28 resident samples with its own parity check."""
+    import torch
+    from gr_adsb_amd import _native
+    from gr_adsb_amd.frontend import FrontEnd
+    from oracle import c_oracle as C
+    out = []
+    log2n = args.extra_log2n
+    n = 1 << log2n
+    cpu_n = 1 << 26
+    specs = [
+        dict(name="config3_8msps_dense", fs=8e6, bursts=6000.0, seed=2, synth={},
+             workload="synthetic 8 Msps complex64 IQ (4x oversampled), 6000 DF17-length bursts/s (72 %% duty, overlapping), AWGN 1e-3"),
+        dict(name="config4_20msps_8_shards_on_one_gpu", fs=20e6, bursts=1000.0, seed=3, synth={}, shards=8,
+             workload="synthetic 20 Msps complex64 IQ, 1000 bursts/s, processed as 8 overlapped time shards on this GPU, host stitch"),
+        dict(name="config5_mixed_df_low_snr", fs=2e6, bursts=1000.0, seed=4,
+             synth=dict(noise_power=2e-3, df_choices=DF_MIX[0], df_weights=DF_MIX[1], snr_db_range=(3.0, 25.0)),
+             workload="synthetic 2 Msps complex64 IQ, 1000 bursts/s mixed DF 0/4/5/11 (56 bit) and 17/20/21 (112 bit) in the "
+                      "proportions of docs/DF_histogram.txt, per-burst SNR 3-25 dB over noise power 2e-3"),
+    ]
+    for sp in specs:
+        fs, sps = sp["fs"], int(sp["fs"] // 1e6)
+        iq = gen_stream_blocks(n, 0, fs, sp["bursts"], sp["seed"], dev, **sp["synth"])
+        torch.cuda.synchronize()
+        fe = FrontEnd(fs, args.threshold, device=dev.index, timing=True)
+        ms, times, st, nb, iso_ms = run_single_gpu_config(fe, _native.FMT_FC32, iq, n, args.extra_steps, 3, args.extra_min_time, depth)
+        rec = {"name": sp["name"], "workload": sp["workload"] + "; 2^%d samples per step resident in HBM" % log2n,
+               "fs": fs, "value": round(n / ms / 1e3, 1), "unit": "Msamples/s", "ms_per_step": round(ms, 4),
+               "steps": args.extra_steps, "repeats": len(times), "bursts_per_step": int(nb),
+               "longrun_calls": int(st["longrun_calls"]), "retries": int(st["retries"]),
+               "roofline": roofline_of(st, "fc32", iso_ms)}
+        # parity: the GPU pass over the first 2^26 samples against the scalar C port of the reference path
+        host = iq[:cpu_n].cpu().numpy().view(np.complex64).reshape(-1)
+        t0 = time.perf_counter()
+        crecs = C.process_iq(host, sps, args.threshold)
+        tc = time.perf_counter() - t0
+        grecs = fe.process_iq_tensor(iq[:cpu_n].contiguous(), 0)
+        rec["bit_match"] = {"sample_bursts": int(len(crecs)), "identical": recs_match(grecs, crecs),
+                            "sample": "first 2^26 samples vs oracle/adsb_oracle.c"}
+        rec["cpu_c_port_msamples_per_s"] = round(cpu_n / tc / 1e6, 1)
+        if sp.get("shards"):
+            whole = fe.process_iq_tensor(iq, 0)
+            one_step = sharded_on_one_gpu(fe, iq, n, sps, sp["shards"], depth)
+            stitched = one_step(True)
+            for _ in range(2):
+                one_step(False)
+            torch.cuda.synchronize()
+            tt = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    one_step(False)
+                torch.cuda.synchronize()
+                tt.append((time.perf_counter() - t0) / 4)
+            msh = float(np.median(tt)) * 1e3
+            rec["sharded"] = {"shards": sp["shards"], "value": round(n / msh / 1e3, 1), "unit": "Msamples/s",
+                              "ms_per_step": round(msh, 4),
+                              "note": "one step = all %d shards submitted %d deep + host fix-up of every head" % (sp["shards"], depth),
+                              "stitched_equals_single_call": recs_match(stitched, whole) and bool(
+                                  np.array_equal(stitched["flags"] & 0x1FE1, whole["flags"] & 0x1FE1)),
+                              "bursts": int(len(whole))}
+        out.append(rec)
+        del iq, fe
+        torch.cuda.empty_cache()
+    return out
+
+
+def host_fed_record(args, fe, iq, fmt, depth):
+    """PCIe-inclusive rates of the host-fed entry point (adsb_submit_format_host), next to a plain pinned H2D copy of
+    the same chunks measured in the same run.  Never the bench `value`."""
+    import torch
+    from gr_adsb_amd import _native
+    chunk = min(iq.shape[0], 1 << args.hostfed_log2n)
+    nbuf = 4
+    pinned = [torch.empty((chunk, 2), dtype=torch.float32).pin_memory() for _ in range(nbuf)]
+    for k, p in enumerate(pinned):
+        p.copy_(iq[k * chunk:(k + 1) * chunk] if (k + 1) * chunk <= iq.shape[0] else iq[:chunk])
+    torch.cuda.synchronize()
+    bytes_per = chunk * 8
+    # plain pinned H2D of the same chunks, back to back on one stream
+    dst = torch.empty((chunk, 2), dtype=torch.float32, device=iq.device)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        dst.copy_(pinned[0], non_blocking=True)
+        st.synchronize()
+        reps = 12
+        t0 = time.perf_counter()
+        for k in range(reps):
+            dst.copy_(pinned[k % nbuf], non_blocking=True)
+        st.synchronize()
+        h2d = reps * bytes_per / (time.perf_counter() - t0) / 1e9
+
+    def run(srcs, reps):
+        pend, nb = [], 0
+        for k in range(2):                                 # warm: device input buffers of the slots, staging ring
+            fe.ctx.wait(fe.ctx.submit_format_host(fmt, srcs[k % len(srcs)]), fetch=False)
+        t0 = time.perf_counter()
+        for k in range(reps):
+            pend.append(fe.ctx.submit_format_host(fmt, srcs[k % len(srcs)]))
+            if len(pend) == depth:
+                nb = fe.ctx.wait(pend.pop(0), fetch=False)
+        while pend:
+            nb = fe.ctx.wait(pend.pop(0), fetch=False)
+        dt = time.perf_counter() - t0
+        return reps * chunk / dt / 1e6, reps * bytes_per / dt / 1e9, nb
+
+    views = [p.numpy().view(np.complex64).reshape(-1) for p in pinned]
+    p_msps, p_gbs, nb = run(views, 12)
+    pageable = [v.copy() for v in views[:2]]
+    g_msps, g_gbs, _ = run(pageable, 6)
+    del pinned, dst
+    return {"entry_point": "adsb_submit_format_host, %d chunks in flight" % depth, "chunk_samples": chunk,
+            "bursts_per_chunk": int(nb),
+            "pinned": {"value": round(p_msps, 1), "unit": "Msamples/s", "gbytes_per_s": round(p_gbs, 2)},
+            "pageable": {"value": round(g_msps, 1), "unit": "Msamples/s", "gbytes_per_s": round(g_gbs, 2),
+                         "note": "copied through two pinned 16 MiB chunks by one host thread, CPU copy overlapping the DMA"},
+            "plain_pinned_h2d_gbytes_per_s": round(h2d, 2), "pinned_vs_plain_h2d": round(p_gbs / h2d, 3)}
 
 
 def main():
@@ -94,12 +375,25 @@ def main():
     ap.add_argument("--bursts", type=float, default=1000.0, help="bursts per second of signal")
     ap.add_argument("--threshold", type=float, default=0.01)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-log2n", type=int, default=28, help="log2 of the CPU-baseline sample (default: one whole step)")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--min-time", type=float, default=0.6, help="seconds of timed region to accumulate (repeats of K steps)")
+    ap.add_argument("--cpu-log2n", type=int, default=28, help="log2 of the C-port CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines and the bit-match leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (BASELINE configs 3, 4, 5)")
+    ap.add_argument("--no-hostfed", action="store_true", help="skip the host-fed (PCIe-inclusive) record")
+    ap.add_argument("--extra-log2n", type=int, default=28)
+    ap.add_argument("--extra-steps", type=int, default=20)
+    ap.add_argument("--extra-min-time", type=float, default=0.25)
+    ap.add_argument("--hostfed-log2n", type=int, default=26)
     ap.add_argument("--format", choices=["fc32", "sc16", "sc8", "cu8"], default="fc32",
                     help="input sample format: complex64 (BASELINE workload), int16 IQ (4 B/sample) or 8-bit IQ "
                          "(2 B/sample: int8 / RTL-SDR offset binary); integer formats N=1 only")
     args = ap.parse_args()
+
+    stray = sorted(k for k in os.environ if k.startswith("ADSB_") and k not in KNOWN_ENV)
+    if stray:
+        print("bench.py: refusing to run with unknown ADSB_* environment variables set: %s" % ", ".join(stray), file=sys.stderr)
+        return 2
+    env_known = {k: os.environ[k] for k in KNOWN_ENV if k in os.environ}
 
     import torch
     import torch.distributed as dist
@@ -128,9 +422,9 @@ def main():
     stream_len = n_own * n_gpus
     fe = FrontEnd(fs, args.threshold, device=local_rank, timing=True)
 
-    sc16 = args.format != "fc32"            # any integer wire format (name kept from the first one added)
+    intfmt = args.format != "fc32"
     fmt = {"fc32": _native.FMT_FC32, "sc16": _native.FMT_SC16, "sc8": _native.FMT_SC8, "cu8": _native.FMT_CU8}[args.format]
-    assert not (sc16 and n_gpus > 1)
+    assert not (intfmt and n_gpus > 1)
     if n_gpus == 1:
         iq = gen_stream_blocks(n_own, 0, fs, args.bursts, args.seed, dev)
         plan = None
@@ -149,8 +443,11 @@ def main():
         iq = gen_stream_blocks(plan["hi"] - plan["lo"], plan["lo"], fs, args.bursts, args.seed, dev)
     torch.cuda.synchronize()
 
-    DEPTH = int(os.environ.get("ADSB_BENCH_DEPTH", _native.MAX_IN_FLIGHT))     # (tuning aid: needs a library built with that many slots)
+    DEPTH = _native.MAX_IN_FLIGHT
     pending = []          # tickets of submitted, not yet collected passes (pipeline of DEPTH passes)
+    host_t = {"stitch": 0.0}
+    stash = {}            # results of tickets that had to be collected early (fallback path only)
+    last_kept = [None]    # N>1: this rank's exact kept bursts of the last collected pass (seam check)
 
     def step():
         if n_gpus == 1:
@@ -167,9 +464,6 @@ def main():
             return collect_shard(pending.pop(0))
         return 0
 
-    host_t = {"stitch": 0.0}
-    stash = {}            # results of tickets that had to be collected early (fallback path only)
-
     def ungated():
         # fallback of sharding.finish_shard: a blocking call is only allowed with no ticket pending, so
         # collect (and keep) whatever is still in flight first; every rank takes this path together
@@ -185,10 +479,12 @@ def main():
         t_x = time.perf_counter()
         kept = sharding.finish_shard(recs, sps, rank, ag_int, ungated, ag_obj, inplace=inplace)
         host_t["stitch"] += time.perf_counter() - t_x
+        last_kept[0] = kept
         return len(kept)
 
     # 16 bytes per rank per pass, host side: shared-memory mailbox on one node, gloo all_gather across nodes
     ag_int, ag_close = sharding.make_pair_exchange(dist, rank, n_gpus) if n_gpus > 1 else (None, lambda: None)
+    transport = None if n_gpus == 1 else ("shm mailbox" if getattr(ag_int, "__self__", None) is not None else "gloo all_gather")
 
     def ag_obj(o):
         out = [None] * n_gpus
@@ -222,9 +518,14 @@ def main():
             dist.all_reduce(torch.zeros(1, device=sync_dev[0]))      # barrier
             torch.cuda.synchronize()
 
-    # the same kernel timed without a neighbour, BEFORE the timed region (it also brings a fresh box's clocks up):
-    # blocking passes, nothing else on the GPU -- in the pipelined timed region below k_burst of pass i runs beside
-    # k_detect of pass i+1 and takes some of its bandwidth
+    def reduce_max(t):
+        if n_gpus == 1:
+            return t
+        tmax = torch.tensor([t], dtype=torch.float64, device=sync_dev[0])
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
+
+    # the same kernel timed without a neighbour, BEFORE the timed region (it also brings a fresh box's clocks up)
     iso_ms = None
     if n_gpus == 1:
         for _ in range(3):
@@ -239,27 +540,36 @@ def main():
         step()
     drain()
     fe.ctx.reset_stats()
-    sync_all()
-    t0 = time.perf_counter()
-    n_bursts = 0
-    for _ in range(args.steps):
-        n_bursts = step()
-    n_bursts = drain()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if n_gpus > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=sync_dev[0])
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    own_times = []
+
+    def reduce_and_keep(t):
+        own_times.append(t)
+        return reduce_max(t)
+
+    times, n_bursts = timed_repeats(step, drain, sync_all, reduce_and_keep, args.steps, args.min_time)
+    elapsed = float(np.median(times))
     st = fe.stats()
+
+    # every rank reports; rank 0 prints (N>1: the record says what each rank saw)
+    per_rank = None
+    seam = None
+    if n_gpus > 1:
+        me = {"rank": rank, "device": torch.cuda.current_device(), "pci_bus_id": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None),
+              "ms_per_step_min": round(min(own_times) / args.steps * 1e3, 4), "ms_per_step_max": round(max(own_times) / args.steps * 1e3, 4),
+              "kernel_ms": round(st["detect_ms"] / max(1, st["detect_launches"]), 4),
+              "stitch_ms_per_step": round(host_t["stitch"] / max(1, args.steps * len(times) + args.warmup) * 1e3, 4),
+              "stitch_fallbacks": sharding.STATS["fallbacks"], "bursts_per_step": int(n_bursts)}
+        per_rank = ag_obj(me)
+        if not one_gpu:
+            assert len({r["device"] for r in per_rank}) == n_gpus or len({r["pci_bus_id"] for r in per_rank}) == n_gpus, \
+                "ranks share a GPU (set ADSB_BENCH_ONE_GPU=1 if that is intended)"
+        seam = seam_check(args, fe, dev, rank, n_gpus, sps, n_own, stream_len, last_kept[0], ag_obj)
 
     result = None
     if rank == 0:
         total_samples = float(n_own) * n_gpus * args.steps
         value = total_samples / elapsed / 1e6
-        kern_ms = st["detect_ms"] / max(1, st["detect_launches"])
-        alg_bytes = st["detect_bytes"] / max(1, st["detect_launches"])
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(fs, args.log2n, args.bursts) if (n_gpus == 1 and not intfmt) else (None, None)
         result = {
             "metric": "IQ Msamples/s through framer+demod",
             "value": round(value, 1),
@@ -273,6 +583,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if args.format == "fc32" else {"sc16": "i16->f32", "sc8": "i8->f32", "cu8": "u8->f32"}[args.format],
             "data": "synthetic",
+            "timing": {"repeats": len(times), "steps_per_repeat": args.steps, "timed_seconds": round(sum(times), 4),
+                       "ms_per_step_min": round(min(times) / args.steps * 1e3, 4),
+                       "ms_per_step_median": round(elapsed / args.steps * 1e3, 4),
+                       "ms_per_step_max": round(max(times) / args.steps * 1e3, 4),
+                       "note": "each repeat = exactly `steps` steps between barrier+synchronize, max over ranks; value uses the median repeat"},
             "config": {
                 "workload": "synthetic %g Msps %s IQ, %g DF17-length bursts/s, AWGN 1e-3, threshold %g; "
                             "2^%d samples per GPU per step resident in HBM; one canonical framer+demod pass"
@@ -281,57 +596,58 @@ def main():
                 "sharding": "none" if n_gpus == 1 else "%d overlapped time shards, host stitch" % n_gpus,
                 "pipeline": "%d passes in flight (submit/wait)" % DEPTH,
                 "detect_gap_ms_avg": round(st["detect_gap_ms"] / max(1, st["detect_gaps"]), 4),
-                "stitch_ms_per_step_rank0": None if n_gpus == 1 else round(host_t["stitch"] / max(1, args.steps + args.warmup) * 1e3, 4),
-                "stitch_fallbacks_rank0": None if n_gpus == 1 else sharding.STATS["fallbacks"],
                 "detect_grid": int(st["detect_grid"]), "retries": int(st["retries"]), "longrun_calls": int(st["longrun_calls"]),
+                "env": env_known,
             },
-            "roofline": {
-                "bound": "hbm", "kernel": "k_detect<%s>" % args.format,
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
-                "kernel_only_msamples_per_s": round(st["detect_samples"] / max(1, st["detect_launches"]) / (kern_ms * 1e-3) / 1e6, 1) if kern_ms > 0 else 0.0,
-                "isolated": None if iso_ms is None else {
-                    "kernel_ms": round(iso_ms, 4), "achieved": round(alg_bytes / (iso_ms * 1e-3) / 1e9, 1),
-                    "frac": round(alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "note": "same kernel, blocking passes, no concurrent k_burst of the previous pass"},
-                "traffic": pmc_traffic(fs, args.log2n, args.bursts) if (n_gpus == 1 and not sc16) else None,
-                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
-            },
+            "roofline": roofline_of(st, args.format, iso_ms),
         }
-        if not args.no_cpu and n_gpus == 1 and not sc16:
+        result["roofline"]["kernel_only_msamples_per_s"] = round(
+            st["detect_samples"] / max(1, st["detect_launches"]) / (result["roofline"]["kernel_ms"] * 1e-3) / 1e6, 1)
+        result["roofline"]["traffic"] = traffic
+        result["roofline"]["traffic_source"] = traffic_src or "none for this workload (see profiles/)"
+        if n_gpus > 1:
+            result["multi_gpu"] = {"ranks_seen": len(per_rank), "exchange_transport": transport, "per_rank": per_rank,
+                                   "stitch_fallbacks_total": int(sum(r["stitch_fallbacks"] for r in per_rank)),
+                                   "seam_check": seam}
+        if not args.no_cpu and n_gpus == 1 and not intfmt:
             n_cpu = min(n_own, 1 << args.cpu_log2n)
             host = iq[:n_cpu].cpu().numpy().view(np.complex64).reshape(-1)
-            msps, crecs = cpu_baseline(host, sps, args.threshold)
+            msps, crecs = cpu_c_port(host, sps, args.threshold)
             # parity in the same run: the GPU path on the same sample must match the C port bit for bit
             grecs = fe.process_iq_tensor(iq[:n_cpu].contiguous(), 0)
-            match = (len(grecs) == len(crecs) and np.array_equal(grecs["offset"], crecs["offset"])
-                     and np.array_equal(grecs["bits"], crecs["bits"])
-                     and np.array_equal(grecs["median"].view(np.uint32), crecs["median"].view(np.uint32))
-                     and np.array_equal(grecs["peak"].view(np.uint32), crecs["peak"].view(np.uint32))
-                     and np.array_equal(grecs["flags"] & 1, crecs["flags"] & 1))
+            ncpu = os.cpu_count() or 1
             result["cpu_baseline"] = {
                 "value": round(msps, 1), "unit": "Msamples/s", "cores": 1, "kind": "port",
                 "sample": "first 2^%d samples of the same stream, oracle/adsb_oracle.c (scalar C restatement of "
-                          "the reference path incl. |IQ|^2), best of 5 (about 6 s of CPU work), host has %d cpus" % (int(np.log2(n_cpu)), os.cpu_count()),
+                          "the reference path incl. |IQ|^2), best of 3 (about 3 s of CPU work); host has %d cpus"
+                          % (int(np.log2(n_cpu)), ncpu),
             }
-            result["bit_match"] = {"sample_bursts": int(len(crecs)), "identical": bool(match)}
-            # the reference-STRUCTURED restatement (vectorised threshold/edges + per-pulse Python
-            # loop, oracle/adsb_oracle.py) on one core, next to the scalar C port above
+            result["bit_match"] = {"sample_bursts": int(len(crecs)), "identical": recs_match(grecs, crecs)}
+            nthr = min(64, ncpu)
+            if nthr > 1:
+                result["cpu_baseline"]["c_port_all_threads"] = {
+                    "value": round(cpu_c_port_threads(host, sps, args.threshold, nthr), 1), "unit": "Msamples/s",
+                    "threads": nthr, "note": "same C port, one contiguous shard of the sample per host thread, no stitch"}
             from oracle import adsb_oracle as O
             n_np = min(n_cpu, 1 << 24)
+            x_np = O.mag2(host[:1 << 26]) if n_cpu >= (1 << 26) else O.mag2(host)
             t_np = time.perf_counter()
-            o_np = O.run_stream(O.mag2(host[:n_np]), fs, args.threshold)
+            o_np = O.run_stream(x_np[:n_np], fs, args.threshold)
             t_np = time.perf_counter() - t_np
-            result["cpu_baseline"]["numpy_port"] = {
+            result["cpu_baseline"]["vectorised_numpy_oracle"] = {
                 "value": round(n_np / t_np / 1e6, 1), "unit": "Msamples/s", "cores": 1,
-                "sample": "first 2^%d samples, oracle/adsb_oracle.py (NumPy restatement with the reference's structure), %d tags"
-                          % (int(np.log2(n_np)), len(o_np["tag_offsets"]))}
-            nthr = min(64, os.cpu_count() or 1)
-            if nthr > 1:
-                result["cpu_baseline"]["all_threads"] = {
-                    "value": round(cpu_baseline_threads(host, sps, args.threshold, nthr), 1), "unit": "Msamples/s",
-                    "threads": nthr, "note": "same C port, one contiguous shard of the sample per host thread"}
+                "sample": "first 2^%d samples of |IQ|^2, oracle/adsb_oracle.py (all pulses matched at once, Python only "
+                          "over matches: faster than the reference's structure), %d tags" % (int(np.log2(n_np)), len(o_np["tag_offsets"]))}
+            result["cpu_baseline"]["reference_structured"] = cpu_reference_structured(x_np, fs, args.threshold, min(64, ncpu))
+            result["cpu_baseline"]["reference_structured"]["what"] = (
+                "oracle/ref_structured.py: vectorised threshold/edges + per-PULSE Python loop + np.median, the cost "
+                "structure of framer.py:83-174 / demod.py:67-110 (|IQ|^2 given); pinned to the goldens and the real reference")
+        if n_gpus == 1 and not intfmt and not args.no_hostfed:
+            result["host_fed"] = host_fed_record(args, fe, iq, fmt, DEPTH)
+        if n_gpus == 1 and not intfmt and not args.no_extra:
+            del iq
+            torch.cuda.empty_cache()
+            result["extra_configs"] = extra_configs(args, dev, DEPTH)
         print(json.dumps(result), flush=True)
     if n_gpus > 1:
         sync_all()
@@ -340,5 +656,34 @@ def main():
     return result
 
 
+def seam_check(args, fe, dev, rank, n_gpus, sps, n_own, stream_len, kept, ag_obj):
+    """N>1 exactness evidence at full size: around every shard seam, ONE canonical call over a window that straddles
+    the seam (regenerated from the deterministic stream) must report exactly the bursts the two neighbouring ranks
+    reported there.  The window call starts from fresh state half a window before the compared region; it re-joins
+    the true gate state at the first pulse-free stretch longer than 63*sps, long before that region."""
+    W = min(1 << 21, n_own // 2)
+    lo_cmp = lambda s: s - W // 2                                   # noqa: E731
+    hi_cmp = lambda s: s + W - 200 * sps                            # noqa: E731
+    seams = [r * n_own for r in range(1, n_gpus)]
+    mine = []                                                       # my records near my two seams
+    for s in seams:
+        m = (kept["offset"] >= lo_cmp(s)) & (kept["offset"] < hi_cmp(s))
+        mine.append(kept[m].copy())
+    everyone = ag_obj(mine)
+    ok, nrec = True, 0
+    if rank >= 1:
+        s = rank * n_own
+        win = gen_stream_blocks(2 * W, s - W, args.fs, args.bursts, args.seed, dev)
+        recs = fe.process_iq_tensor(win, s - W)
+        recs = recs[(recs["offset"] >= lo_cmp(s)) & (recs["offset"] < hi_cmp(s))]
+        theirs = np.concatenate([everyone[r][rank - 1] for r in range(n_gpus)])
+        theirs = theirs[np.argsort(theirs["offset"], kind="stable")]
+        ok = recs_match(recs, theirs)
+        nrec = len(recs)
+    res = ag_obj({"rank": rank, "identical": bool(ok), "bursts_compared": int(nrec)})
+    return {"window_samples": 2 * W, "per_seam": res[1:], "all_identical": all(r["identical"] for r in res)}
+
+
 if __name__ == "__main__":
-    main()
+    rc = main()
+    sys.exit(rc if isinstance(rc, int) else 0)

@@ -131,11 +131,15 @@ def dequantize_iq16(q, full_scale=2.0):
     return (v[0::2] + 1j * v[1::2]).astype(np.complex64)
 
 
-def synth_iq_torch(n, fs, bursts_per_s, seed, device, noise_power=1e-3, amp2_range=(0.05, 1.0)):
-    """Same kind of stream as synth_iq (DF17-length random-payload bursts), generated in HBM.
+def synth_iq_torch(n, fs, bursts_per_s, seed, device, noise_power=1e-3, amp2_range=(0.05, 1.0),
+                   df_choices=None, df_weights=None, snr_db_range=None):
+    """Same kind of stream as synth_iq, generated in HBM: by default DF17-length random-payload bursts.
 
     Returns a float32 tensor of shape [n, 2] (interleaved I,Q == complex64 memory layout).
     Payload bits are random (parity irrelevant to framer/demod); layout/amplitudes match synth_iq.
+    df_choices / df_weights: per-burst downlink format (its five bits lead the payload; SHORT_DFS bursts end after
+    56 bits -- BASELINE config 5's mix).  snr_db_range: burst power = noise_power * 10^(U(range)/10) instead of
+    amp2_range.
     """
     import torch
 
@@ -153,9 +157,24 @@ def synth_iq_torch(n, fs, bursts_per_s, seed, device, noise_power=1e-3, amp2_ran
     bits = torch.randint(0, 2, (nb, 112), device=device, generator=g, dtype=torch.int64)
     pre = torch.tensor(PREAMBLE_CHIPS.astype(np.int64), device=device).expand(nb, 16)
     data = torch.stack([bits, 1 - bits], dim=2).reshape(nb, 224)
+    if df_choices is not None:
+        w = torch.tensor(np.asarray(df_weights if df_weights is not None else np.ones(len(df_choices)), dtype=np.float64),
+                         device=device)
+        pick = torch.multinomial(w / w.sum(), nb, replacement=True, generator=g)
+        dfs = torch.tensor(np.asarray(df_choices, dtype=np.int64), device=device)[pick]
+        for k in range(5):
+            bits[:, k] = (dfs >> (4 - k)) & 1
+        short = torch.zeros(nb, dtype=torch.bool, device=device)
+        for d in SHORT_DFS:
+            short |= dfs == d
+        data = torch.stack([bits, 1 - bits], dim=2).reshape(nb, 224)
+        data[:, 112:] *= (~short).to(torch.int64)[:, None]          # a 56-bit reply is silent after its last bit
     chips = torch.cat([pre, data], dim=1).to(torch.float32)  # [nb, 240]
     env = chips.repeat_interleave(half, dim=1)  # [nb, blen]
-    p = torch.empty(nb, device=device).uniform_(amp2_range[0], amp2_range[1], generator=g)
+    if snr_db_range is not None:
+        p = noise_power * torch.pow(10.0, torch.empty(nb, device=device).uniform_(snr_db_range[0], snr_db_range[1], generator=g) / 10.0)
+    else:
+        p = torch.empty(nb, device=device).uniform_(amp2_range[0], amp2_range[1], generator=g)
     ph = torch.empty(nb, device=device).uniform_(0.0, 2 * np.pi, generator=g)
     a = torch.sqrt(p)
     idx = (starts[:, None] + torch.arange(blen, device=device)[None, :]).reshape(-1)

@@ -4,7 +4,7 @@
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; nothing under
  * gr_adsb_amd/ does.  It is pinned against oracle/adsb_oracle.py (which is pinned against the real
- * reference, see that file's header) by tests/test_oracle_c.py, and used where the NumPy oracle is
+ * reference, see that file's header) by tests/test_oracle_golden.py, and used where the NumPy oracle is
  * too slow: full-size parity checks and the single-core CPU baseline ("kind": "port").
  *
  * Citations are to /root/reference/python/adsb/.  |IQ|^2 (GNU Radio complex_to_mag_squared,

@@ -82,3 +82,49 @@ def assert_recs_equal(a, b, what=""):
     for r in (a, b):                       # device-produced side(s): the oracle's framer records carry no parity bits
         if np.any(r["flags"] & PARITY_BITS):
             assert_parity_flags(r, what)
+
+
+# ---- the gnuradio.adsb drop-in (packaging/gnuradio_adsb) evaluated the way GRC does, without GNU Radio -----------
+def load_gnuradio_adsb():
+    """Import packaging/gnuradio_adsb/adsb/__init__.py as `gnuradio.adsb` under a stub `gnuradio` package (the test
+    double of the GNU Radio runtime, gr_adsb_amd/grshim.py) unless a real GNU Radio is importable."""
+    import importlib.util
+    import sys
+    import types
+    from gr_adsb_amd import grshim
+    if "gnuradio" not in sys.modules:
+        try:
+            import gnuradio  # noqa: F401
+        except ImportError:
+            pkg = types.ModuleType("gnuradio")
+            pkg.__path__ = []
+            pkg.gr = grshim
+            sys.modules["gnuradio"] = pkg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "packaging", "gnuradio_adsb", "adsb", "__init__.py")
+    spec = importlib.util.spec_from_file_location("gnuradio.adsb", path, submodule_search_locations=[os.path.dirname(path)])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["gnuradio.adsb"] = mod
+    spec.loader.exec_module(mod)
+    sys.modules["gnuradio"].adsb = mod
+    return mod
+
+
+def grc_instantiate(descriptor, **overrides):
+    """What GRC's generated flowgraph script does with a block descriptor (dict from the .block.yml): run
+    `templates.imports`, evaluate `templates.make` with the parameter values substituted for ${id}.  Returns
+    (block, callbacks) -- callbacks(name=value, ...) evaluates the descriptor's callback templates on the block."""
+    import re
+    # GRC keeps parameter values as Python expressions (the text `2e6` is a string to a YAML 1.1 parser) and evaluates them
+    params = {p["id"]: (eval(p["default"]) if isinstance(p.get("default"), str) else p.get("default")) for p in descriptor["parameters"]}
+    params.update(overrides)
+    ns = {}
+    exec(descriptor["templates"]["imports"], ns)
+    sub = lambda t, vals: re.sub(r"\$\{(\w+)\}", lambda m: repr(vals[m.group(1)]), t)     # noqa: E731
+    blk = eval(sub(descriptor["templates"]["make"], params), ns)
+
+    def callbacks(**new):
+        vals = dict(params, **new)
+        for cb in descriptor["templates"].get("callbacks", []):
+            eval("blk." + sub(cb, vals), dict(ns, blk=blk))
+    return blk, callbacks

@@ -108,6 +108,8 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
 }
 
 void sim_set_long_aware(int v) { g_long_aware = v; }
+// the kernel's tile geometry, so that seam-targeted tests follow it
+void sim_geometry(int* tile, int* fwd, int* back) { *tile = kWTile; *fwd = kFwd; *back = kBack; }
 void sim_set_confidence_out(float* p) { g_conf_out = p; }
 
 // --- the library's three call shapes, through the same adsb_plan.h the library uses ------------------

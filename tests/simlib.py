@@ -43,6 +43,13 @@ def lib():
     return _lib
 
 
+def kernel_geometry():
+    """(tile, forward halo, back halo) of k_detect's sliding LDS window, from the compiled device header."""
+    t, f, b = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    lib().sim_geometry(ctypes.byref(t), ctypes.byref(f), ctypes.byref(b))
+    return t.value, f.value, b.value
+
+
 def sim_run(mode, data, sps, thr, in0_base, scan_lo, scan_hi, fall_hi, dem_hi, origin=0, prev_in0=0.0,
             end_is_call_end=1, prev_eob_stream=None, gate=True, grid_max=6, rec_cap=0, scale=1.0):
     """mode 0: complex64[n]; 1: float32 |IQ|^2 [n]; 2: int16 / 3: int8 / 4: uint8 interleaved IQ [2n]."""

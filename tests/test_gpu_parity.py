@@ -715,6 +715,32 @@ def test_adversarial_streams(native):
     assert checked > 100
 
 
+@pytest.mark.parametrize("name", ["g2msps_df17", "g8msps_dense"])
+@pytest.mark.parametrize("sched", ["single", "random"])
+def test_gnuradio_adsb_namespace_drives_goldens(native, name, sched):
+    """the blocks instantiated the way GRC does -- `import gnuradio.adsb as adsb`, then the descriptor's
+    make template `adsb.framer(${fs}, ${threshold})` / `adsb.demod(${fs})` with the ids, parameters and callbacks of the
+    reference's descriptors (packaging/gnuradio_adsb/grc; tests/test_packaging.py proves them equal to the
+    reference's) -- produce the reference's tags and PDUs."""
+    import os
+    import yaml
+    from gr_adsb_amd import grshim
+    from helpers import grc_instantiate, load_gnuradio_adsb
+    load_gnuradio_adsb()
+    g = Golden(name)
+    grc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "packaging", "gnuradio_adsb", "grc")
+    fr, fr_cb = grc_instantiate(yaml.safe_load(open(os.path.join(grc, "adsb_framer.block.yml"))), fs=g.fs, threshold=0.5)
+    dm, _ = grc_instantiate(yaml.safe_load(open(os.path.join(grc, "adsb_demod.block.yml"))), fs=g.fs)
+    fr_cb(threshold=g.thr)                           # the descriptor's set_threshold callback, before the first work()
+    dm.start_timestamp = 0.0
+    tags, msgs = grshim.drive(fr, dm, g.x, None if sched == "single" else g.sched(sched))
+    assert np.array_equal(np.array([t.offset for t in tags], dtype=np.int64), g.get(sched, "tag_offsets"))
+    snr = np.array([t.value[1] for t in tags], dtype=np.float32)
+    assert np.array_equal(snr.view(np.uint32), g.get(sched, "tag_snr_bits"))
+    bits = np.array([m[1] for _, m in msgs], dtype=np.uint8).reshape(-1, 112)
+    assert np.array_equal(bits, g.pdu_bits(sched))
+
+
 def test_host_fed_pipeline_equals_blocking_calls(native):
     """adsb_submit_format_host: chunks in host memory (page-locked: DMA'd where they lie; pageable: through the
     pinned chunk ring, > 16 MiB so that the ring wraps), three in flight, == the blocking entry points == the oracle."""

@@ -1,0 +1,113 @@
+"""The N>1 PRODUCT path on the GPU box (-m gpu): two ranks -- two processes, each with its own context on cuda:0 -- run
+the overlapped-time-shard pipeline of bench.py --gpus N: device pass per shard, the shared-memory tail exchange,
+adsb_shard_fixup, and the full-candidate fallback.  (The driver's box has one GPU: ADSB_BENCH_ONE_GPU / device 0 for
+both ranks exercises the code path, not the scaling.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _stream(case, n):
+    from gr_adsb_amd import modulator as M
+    if case == "chain":
+        # clean preambles every 100 samples (< the 126-sample gate): one unbroken chain through every shard seam, so a
+        # shard's first centres are decided by its predecessor's tail and no head region can re-synchronise
+        x = np.full(n, 1e-4, dtype=np.float32)
+        for base in range(50, n - 400, 100):
+            x[base + np.array([0, 2, 7, 9])] = 1.0
+        return np.sqrt(x).astype(np.complex64)
+    return M.synth_iq(n, 2e6, 3000, seed=23)
+
+
+def _worker(rank, world, port, case, n, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_WORLD_SIZE"] = str(world)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gr_adsb_amd import _native, sharding
+    from gr_adsb_amd.frontend import shard_plan
+    fs, sps = 2e6, 2
+    iq = _stream(case, n)
+    p = shard_plan(n, world, sps, align=4)[rank]
+    ctx = _native.Context(fs, 0.01, device=0)
+
+    def shard(head):
+        return ctx.shard_host(_native.FMT_FC32, iq[p["lo"]:p["hi"]], p["lo"], p["own_lo"], p["own_hi"], n, head_cands=head)
+
+    ag_pair, ag_close = sharding.make_pair_exchange(dist, rank, world)
+    assert ag_pair.__self__.__class__.__name__ == "ShmPairExchange"
+
+    def ag_obj(o):
+        out = [None] * world
+        dist.all_gather_object(out, o)
+        return out
+
+    before = sharding.STATS["fallbacks"]
+    kept = sharding.finish_shard(shard(sharding.HEAD_CANDS), sps, rank, ag_pair, lambda: shard(0), ag_obj)
+    allk = ag_obj((kept, sharding.STATS["fallbacks"] - before))
+    if rank == 0:
+        q.put((np.concatenate([k for k, _ in allk]).tobytes(), [f for _, f in allk]))
+    dist.barrier()
+    ag_close()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,n,world", [("synthetic", 1 << 18, 2), ("chain", 30000, 2), ("chain", 1500, 3), ("synthetic", 70000, 4)])
+def test_ranks_on_gpu_equal_one_canonical_call(case, n, world):
+    import torch.multiprocessing as mp
+    from gr_adsb_amd import _native
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    raw, fallbacks = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    got = np.frombuffer(raw, dtype=_native.BURST_DTYPE)
+    want = _native.Context(2e6, 0.01).process_iq(_stream(case, n))          # ONE canonical call on the same GPU
+    assert len(want) > 5
+    assert np.array_equal(got["offset"], want["offset"])
+    assert np.array_equal(got["bits"], want["bits"])
+    assert np.array_equal(got["median"].view(np.uint32), want["median"].view(np.uint32))
+    assert np.array_equal(got["flags"] & 0x1FE1, want["flags"] & 0x1FE1)
+    assert len(set(fallbacks)) == 1                                          # every rank took the same decision
+    assert (fallbacks[0] > 0) == (case == "chain")                           # the chain cannot be fixed up locally
+
+
+def test_bench_two_ranks_one_gpu_seam_check():
+    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run), both ranks on cuda:0."""
+    env = dict(os.environ, ADSB_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--log2n", "23", "--min-time", "0.05"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    mg = d["multi_gpu"]
+    assert mg["ranks_seen"] == 2 and mg["exchange_transport"] == "shm mailbox"
+    assert mg["seam_check"]["all_identical"] and mg["seam_check"]["per_seam"][0]["bursts_compared"] > 100
+    assert [r_["rank"] for r_ in mg["per_rank"]] == [0, 1]

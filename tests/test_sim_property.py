@@ -12,7 +12,11 @@ from gr_adsb_amd import modulator as M
 from oracle import adsb_oracle as O
 from oracle import c_oracle as C
 
-TILE, WIN = 4096, 4352
+# the kernel's real seams (adsb_device.h): one wavefront walks 1024-sample tiles through a sliding LDS window that
+# holds 128 samples behind and 256 samples beyond the tile; a pulse longer than the window goes to k_longrun
+TILE, FWD, BACK = simlib.kernel_geometry()
+WIN = TILE + FWD
+assert (TILE, FWD, BACK) == (1024, 256, 128), "seam-targeted cases below assume this geometry: revisit them"
 
 
 def adversarial_stream(rng, n, sps):
@@ -21,8 +25,9 @@ def adversarial_stream(rng, n, sps):
     x = levels[rng.integers(0, 4, n)].copy()                    # quiet floor with ties
     half = sps // 2
     env = M.burst_waveform(M.make_frame(17, rng), sps)
-    seams = [k * TILE + d for k in range(1, n // TILE + 2) for d in (-300, -257, -256, -255, -130, -17, -16, -2, -1, 0, 1, 15, 16)]
-    seams += [k * TILE + WIN - TILE + d for k in range(1, n // TILE + 1) for d in (-1, 0, 1)]
+    seams = [k * TILE + d for k in range(1, n // TILE + 2)
+             for d in (-300, -257, -256, -255, -240, -130, -129, -128, -127, -101, -100, -99, -17, -16, -2, -1, 0, 1, 15, 16)]
+    seams += [k * TILE + FWD + d for k in range(0, n // TILE + 1) for d in (-1, 0, 1)]        # the window's far edge
     for _ in range(int(rng.integers(0, 12))):                   # bursts, preferably starting at a seam
         s = int(rng.choice(seams)) if rng.random() < 0.7 else int(rng.integers(0, n))
         s = max(0, min(n - 1, s))
@@ -32,7 +37,7 @@ def adversarial_stream(rng, n, sps):
     for _ in range(int(rng.integers(0, 10))):                   # plateaus of awkward lengths
         s = int(rng.choice(seams)) if rng.random() < 0.7 else int(rng.integers(0, n))
         s = max(0, min(n - 1, s))
-        ln = int(rng.choice([1, 2, 3, 63, 64, 65, 255, 256, 257, 300, 4095, 4096, 4097, 5000]))
+        ln = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 1023, 1024, 1025, 1279, 1280, 1281, 2500]))
         x[s:min(n, s + ln)] = levels[rng.integers(4, 10)]
     for _ in range(int(rng.integers(0, 40))):                   # isolated short pulses
         s = int(rng.integers(0, n))
@@ -44,9 +49,9 @@ def adversarial_stream(rng, n, sps):
 
 @settings(max_examples=150, deadline=None, suppress_health_check=list(HealthCheck))
 @given(seed=st.integers(0, 2**31 - 1),
-       n=st.sampled_from([1, 17, 240, 4095, 4096, 4097, 4111, 4352, 8191, 8192, 8193, 12288, 20000]),
+       n=st.sampled_from([1, 17, 240, 1023, 1024, 1025, 1279, 1280, 1281, 2047, 2048, 2049, 3333, 4096, 4352, 8193, 12288]),
        sps=st.sampled_from([2, 4, 8, 20]),
-       thr=st.sampled_from([0.01, 0.0099, 0.0101, 0.004, 0.05]))
+       thr=st.sampled_from([0.01, 0.0099, 0.0101, 0.004, 0.05, 0.0, -1.0]))
 def test_canonical_equals_c_oracle_on_adversarial_streams(seed, n, sps, thr):
     rng = np.random.default_rng(seed)
     x = adversarial_stream(rng, n, sps)
@@ -66,7 +71,7 @@ def test_framer_work_random_schedules_equal_numpy_oracle(seed, sps):
     H = 8 * sps
     sched, rem = [], n
     while rem > 0:
-        c = int(min(rem, rng.choice([1, 7, 64, 300, 1000, 4096, 4097, 5000])))
+        c = int(min(rem, rng.choice([1, 7, 64, 300, 1000, 1023, 1024, 1025, 1280, 4097, 5000])))
         sched.append(c)
         rem -= c
     o = O.run_stream(x, fs, 0.01, sched)

@@ -680,6 +680,10 @@ def seam_check(args, fe, dev, rank, n_gpus, sps, n_own, stream_len, kept, ag_obj
         theirs = theirs[np.argsort(theirs["offset"], kind="stable")]
         ok = recs_match(recs, theirs)
         nrec = len(recs)
+        if not ok:
+            a, b = set(recs["offset"].tolist()), set(theirs["offset"].tolist())
+            print("bench: seam %d differs: window call %d bursts, ranks %d; only in window %s; only in ranks %s"
+                  % (rank, len(recs), len(theirs), sorted(a - b)[:8], sorted(b - a)[:8]), file=sys.stderr)
     res = ag_obj({"rank": rank, "identical": bool(ok), "bursts_compared": int(nrec)})
     return {"window_samples": 2 * W, "per_seam": res[1:], "all_identical": all(r["identical"] for r in res)}
 

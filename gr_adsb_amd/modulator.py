@@ -180,12 +180,19 @@ def synth_iq_torch(n, fs, bursts_per_s, seed, device, noise_power=1e-3, amp2_ran
     idx = (starts[:, None] + torch.arange(blen, device=device)[None, :]).reshape(-1)
     # process in slices to bound temporary memory
     step = max(1, (1 << 24) // blen)
-    for b0 in range(0, nb, step):
-        b1 = min(nb, b0 + step)
-        e = env[b0:b1]
-        wi = (e * (a[b0:b1] * torch.cos(ph[b0:b1]))[:, None]).reshape(-1)
-        wq = (e * (a[b0:b1] * torch.sin(ph[b0:b1]))[:, None]).reshape(-1)
-        ii = idx[b0 * blen:b1 * blen]
-        iq[:, 0].index_add_(0, ii, wi)
-        iq[:, 1].index_add_(0, ii, wq)
+    # overlapping bursts hit the same samples: the accumulation must be order-deterministic (atomics are not), or two
+    # ranks that generate the same block -- the overlap of neighbouring shards -- would differ in the last bit
+    det = torch.are_deterministic_algorithms_enabled()
+    torch.use_deterministic_algorithms(True)
+    try:
+        for b0 in range(0, nb, step):
+            b1 = min(nb, b0 + step)
+            e = env[b0:b1]
+            wi = (e * (a[b0:b1] * torch.cos(ph[b0:b1]))[:, None]).reshape(-1)
+            wq = (e * (a[b0:b1] * torch.sin(ph[b0:b1]))[:, None]).reshape(-1)
+            ii = idx[b0 * blen:b1 * blen]
+            iq[:, 0].index_add_(0, ii, wi)
+            iq[:, 1].index_add_(0, ii, wq)
+    finally:
+        torch.use_deterministic_algorithms(det)
     return iq

@@ -384,6 +384,8 @@ def main():
     ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--extra-min-time", type=float, default=0.25)
     ap.add_argument("--hostfed-log2n", type=int, default=26)
+    ap.add_argument("--single-stream", action="store_true",
+                    help="profiling aid (ADSB_FLAG_SINGLE_STREAM): the sparse tail of a pass behind its k_detect on one stream")
     ap.add_argument("--format", choices=["fc32", "sc16", "sc8", "cu8"], default="fc32",
                     help="input sample format: complex64 (BASELINE workload), int16 IQ (4 B/sample) or 8-bit IQ "
                          "(2 B/sample: int8 / RTL-SDR offset binary); integer formats N=1 only")
@@ -420,7 +422,8 @@ def main():
     sps = int(fs // 1e6)
     n_own = 1 << args.log2n
     stream_len = n_own * n_gpus
-    fe = FrontEnd(fs, args.threshold, device=local_rank, timing=True)
+    fe = FrontEnd(fs, args.threshold, device=local_rank, timing=True,
+                  flags=_native.FLAG_SINGLE_STREAM if args.single_stream else 0)
 
     intfmt = args.format != "fc32"
     fmt = {"fc32": _native.FMT_FC32, "sc16": _native.FMT_SC16, "sc8": _native.FMT_SC8, "cu8": _native.FMT_CU8}[args.format]
@@ -594,7 +597,7 @@ def main():
                             % (fs / 1e6, {"fc32": "complex64", "sc16": "int16", "sc8": "int8", "cu8": "uint8 offset-binary"}[args.format], args.bursts, args.threshold, args.log2n),
                 "fs": fs, "samples_per_gpu_per_step": n_own, "bursts_per_step_rank0": int(n_bursts),
                 "sharding": "none" if n_gpus == 1 else "%d overlapped time shards, host stitch" % n_gpus,
-                "pipeline": "%d passes in flight (submit/wait)" % DEPTH,
+                "pipeline": "%d passes in flight (submit/wait)%s" % (DEPTH, ", single stream" if args.single_stream else ""),
                 "detect_gap_ms_avg": round(st["detect_gap_ms"] / max(1, st["detect_gaps"]), 4),
                 "detect_grid": int(st["detect_grid"]), "retries": int(st["retries"]), "longrun_calls": int(st["longrun_calls"]),
                 "env": env_known,
@@ -673,7 +676,9 @@ def seam_check(args, fe, dev, rank, n_gpus, sps, n_own, stream_len, kept, ag_obj
     ok, nrec = True, 0
     if rank >= 1:
         s = rank * n_own
+        import torch
         win = gen_stream_blocks(2 * W, s - W, args.fs, args.bursts, args.seed, dev)
+        torch.cuda.synchronize()                                   # torch produced it; the context runs on its own stream
         recs = fe.process_iq_tensor(win, s - W)
         recs = recs[(recs["offset"] >= lo_cmp(s)) & (recs["offset"] < hi_cmp(s))]
         theirs = np.concatenate([everyone[r][rank - 1] for r in range(n_gpus)])

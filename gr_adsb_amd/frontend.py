@@ -30,10 +30,10 @@ def shard_plan(stream_len, n_shards, sps, max_run=256, align=4096):
 
 
 class FrontEnd:
-    def __init__(self, fs, threshold, device=0, timing=False):
+    def __init__(self, fs, threshold, device=0, timing=False, flags=0):
         self.fs = float(fs)
         self.sps = int(fs // 1e6)
-        self.ctx = _native.Context(fs, threshold, device=device, flags=_native.FLAG_TIMING if timing else 0)
+        self.ctx = _native.Context(fs, threshold, device=device, flags=int(flags) | (_native.FLAG_TIMING if timing else 0))
 
     def set_threshold(self, thr):
         self.ctx.set_threshold(thr)

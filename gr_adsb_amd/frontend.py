@@ -29,6 +29,15 @@ def shard_plan(stream_len, n_shards, sps, max_run=256, align=4096):
     return plans
 
 
+def _after_torch(t):
+    """The context runs on its own HIP stream: whatever torch still has queued on ITS current stream for this tensor
+    (the kernels that produce it) must have finished before our kernels read it.  A no-op when that stream is idle.
+    (adsb_set_stream / FrontEnd.use_torch_stream is the alternative: share torch's stream and skip this.)"""
+    import torch
+    assert t.is_cuda and t.is_contiguous()
+    torch.cuda.current_stream(t.device).synchronize()
+
+
 class FrontEnd:
     def __init__(self, fs, threshold, device=0, timing=False, flags=0):
         self.fs = float(fs)
@@ -69,42 +78,42 @@ class FrontEnd:
     # -- torch tensors already in HBM ---------------------------------------------------------------
     def process_format_tensor(self, fmt, t, abs_offset=0, fetch=True):
         """t: contiguous CUDA tensor whose first dimension is the sample count ([n,2] for the IQ formats)."""
-        assert t.is_cuda and t.is_contiguous()
+        _after_torch(t)
         return self.ctx.process_format_device(fmt, t.data_ptr(), t.shape[0], abs_offset, fetch=fetch)
 
     def submit_format_tensor(self, fmt, t, abs_offset=0):
-        assert t.is_cuda and t.is_contiguous()
+        _after_torch(t)
         return self.ctx.submit_format_device(fmt, t.data_ptr(), t.shape[0], abs_offset)
 
     def process_iq_tensor(self, t, abs_offset=0, fetch=True):
         """t: float32 [n,2] (or complex64 [n]) CUDA tensor, contiguous."""
-        assert t.is_cuda and t.is_contiguous()
+        _after_torch(t)
         n = t.shape[0]
         return self.ctx.process_iq_device(t.data_ptr(), n, abs_offset, fetch=fetch)
 
     def process_mag2_tensor(self, t, abs_offset=0, fetch=True):
-        assert t.is_cuda and t.is_contiguous()
+        _after_torch(t)
         return self.ctx.process_mag2_device(t.data_ptr(), t.shape[0], abs_offset, fetch=fetch)
 
     def submit_iq16_tensor(self, t, abs_offset=0):
         """t: int16 [n,2] CUDA tensor (interleaved I,Q)."""
-        assert t.is_cuda and t.is_contiguous()
+        _after_torch(t)
         return self.ctx.submit_iq16_device(t.data_ptr(), t.shape[0], abs_offset)
 
     def submit_iq_tensor(self, t, abs_offset=0):
         """Queue a canonical pass over t (up to _native.MAX_IN_FLIGHT in flight); returns a ticket for wait()."""
-        assert t.is_cuda and t.is_contiguous()
+        _after_torch(t)
         return self.ctx.submit_iq_device(t.data_ptr(), t.shape[0], abs_offset)
 
     def submit_shard_tensor(self, t, origin, own_lo, own_hi, stream_len, fmt=0, head_cands=0):
-        assert t.is_cuda and t.is_contiguous()
+        _after_torch(t)
         return self.ctx.submit_shard_device(fmt, t.data_ptr(), t.shape[0], origin, own_lo, own_hi, stream_len, head_cands)
 
     def wait(self, ticket, fetch=True, copy=True):
         return self.ctx.wait(ticket, fetch=fetch, copy=copy)
 
     def shard_tensor(self, t, origin, own_lo, own_hi, stream_len, fmt=0, head_cands=0):
-        assert t.is_cuda and t.is_contiguous()
+        _after_torch(t)
         return self.ctx.shard_device(fmt, t.data_ptr(), t.shape[0], origin, own_lo, own_hi, stream_len, head_cands)
 
     def stitch(self, cand_lists):

@@ -467,7 +467,7 @@ def test_full_size_properties(native, torch_mod):
     fs, sps, n = 2e6, 2, 1 << 28
     iq = M.synth_iq_torch(n, fs, 1000, 1, torch.device("cuda:0"))
     fe = FrontEnd(fs, 0.01)
-    whole = fe.process_iq_tensor(iq)
+    whole = fe.process_iq_tensor(iq)            # (FrontEnd waits for torch's stream: the generator's kernels produce iq)
     assert 100000 < len(whole) < 140000      # 134 s of signal at ~1000 bursts/s, some lost to collisions
     d = np.diff(whole["offset"])
     assert d.min() > 63 * sps

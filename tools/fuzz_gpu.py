@@ -23,6 +23,7 @@ def main():
     _native.load()
     ctxs = {}
     la_ctxs = {}
+    cf_ctxs = {}
     t0 = time.time()
     n_cases = n_bursts = 0
     n_gr = [0]
@@ -75,6 +76,25 @@ def main():
             bits = np.array([m[1] for _, m in msgs], dtype=np.uint8).reshape(-1, 112)
             assert np.array_equal(bits, o["pdu_bits"]), what + " gr pdus"
             n_gr[0] += 1
+        if n >= 1 and rng.random() < 0.3:             # host-fed pipelined submission (pageable source) == blocking call
+            t1 = ctx.submit_format_host(_native.FMT_MAG2, x)
+            t2 = ctx.submit_format_host(_native.FMT_MAG2, x, abs_offset=77)
+            assert_recs_equal(ctx.wait(t1), want, what + " host-fed")
+            r2 = ctx.wait(t2)
+            r2["offset"] -= 77
+            assert_recs_equal(r2, want, what + " host-fed #2")
+        if n <= 20000 and rng.random() < 0.3:         # fused-path confidence ratios (ADSB_FLAG_CONFIDENCE) vs demod.py:97-101
+            cf = cf_ctxs.setdefault(sps, _native.Context(sps * 1e6, thr, flags=_native.FLAG_CONFIDENCE))
+            cf.set_threshold(thr)
+            rc = cf.process_mag2(x)
+            ratio = cf.last_confidence()
+            o = O.run_stream(x, sps * 1e6, thr)
+            assert_recs_equal(rc, want, what + " confidence ctx")
+            dem = (rc["flags"] & 1) != 0
+            gr, wr = ratio[dem], o["pdu_ratio"]
+            assert gr.shape == wr.shape and np.array_equal(gr, wr, equal_nan=True), what + " ratios"
+            fin = ~np.isnan(wr)
+            assert np.array_equal(gr[fin].view(np.uint32), wr[fin].view(np.uint32)), what + " ratio bits"
         if rng.random() < 0.3:                        # opt-in length-aware gate vs its oracle restatement
             la = la_ctxs.setdefault(sps, _native.Context(sps * 1e6, thr, flags=_native.FLAG_LONG_AWARE_GATE))
             la.set_threshold(thr)

@@ -1006,45 +1006,51 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total) {
 }
 
 // ---- k_scan: per-unit counts -> offsets, totals (single workgroup) ---------------------------------
-// Global memory is touched only with COALESCED wave accesses (list b by thread b mod 256): the counts are staged
-// in LDS, the per-thread contiguous ranges of the prefix sum are walked there, and the offsets go back through LDS
-// the same way.  (A version whose threads read their 20 contiguous lists straight from global memory -- 64
-// different cache lines per wave instruction -- was measured to lengthen the CONCURRENT k_detect of the next pass
-// by 0.03 ms; the same kernel with coalesced accesses costs it nothing.)
-constexpr int kScanMaxLists = 8192;          // LDS staging capacity (32 KB); more lists take the direct path
+// Global memory is touched only with COALESCED wave accesses (list b by thread b mod 256): the counts are staged in
+// LDS round by round (kScanRound lists each), the per-thread contiguous ranges of the prefix sum are walked there,
+// and the offsets go back through LDS the same way.  (A version whose threads read their 20 contiguous lists straight
+// from global memory -- 64 different cache lines per wave instruction -- was measured to lengthen the CONCURRENT
+// k_detect of the next pass by 0.03 ms; the same kernel with coalesced accesses costs it nothing.)  4 KB of LDS and
+// few registers on purpose: this workgroup must fit on a CU BESIDE five resident k_detect workgroups (7 KB of LDS and
+// 112 VGPRs per SIMD are free there), or the whole tail of a pass waits for the next pass's k_detect to drain.
+constexpr int kScanRound = 1024;
+constexpr int kScanPer = kScanRound / kThreads;      // 4 consecutive lists per thread and round
 __global__ void __launch_bounds__(kThreads) k_scan(const int* blk_count, const long long* blk_lastp,
                                                    const unsigned* blk_flags, int nblk, int rec_cap,
                                                    const int* long_count, const unsigned long long* long_lastp,
                                                    int* blk_off, Summary* sum) {
   __shared__ long long s_lp[kWaves];
   __shared__ unsigned s_fl[kWaves];
-  __shared__ int s_cnt[kScanMaxLists];
+  __shared__ int s_cnt[kScanRound];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (nblk + kThreads - 1) / kThreads;
-  const int b0 = tid * per;
-  int b1 = b0 + per; if (b1 > nblk) b1 = nblk;
-  const bool staged = nblk <= kScanMaxLists;                  // block-uniform
-  int acc = 0; long long lp = kNoIndex; unsigned fl = 0;
-  if (staged) {
-    for (int b = tid; b < nblk; b += kThreads) {              // coalesced: counts to LDS, max/OR reduced on the fly
-      int c = blk_count[b];
-      if (c > rec_cap) { fl |= 0x80000000u; c = rec_cap; }    // bit 31: some unit overflowed its list
-      s_cnt[b] = c;
-      const long long l = blk_lastp[b];
-      if (l > lp) lp = l;
-      fl |= blk_flags[b];
+  long long lp = kNoIndex; unsigned fl = 0;
+  int carry = 0;                                               // lists before this round hold `carry` centres
+  for (int base = 0; base < nblk; base += kScanRound) {
+    for (int k = tid; k < kScanRound; k += kThreads) {         // coalesced: counts to LDS, max / OR reduced on the fly
+      const int b = base + k;
+      int c = 0;
+      if (b < nblk) {
+        c = blk_count[b];
+        if (c > rec_cap) { fl |= 0x80000000u; c = rec_cap; }  // bit 31: some unit overflowed its list
+        const long long l = blk_lastp[b];
+        if (l > lp) lp = l;
+        fl |= blk_flags[b];
+      }
+      s_cnt[k] = c;
     }
     __syncthreads();
-    for (int b = b0; b < b1; ++b) acc += s_cnt[b];
-  } else {
-    for (int b = b0; b < b1; ++b) {
-      int c = blk_count[b];
-      if (c > rec_cap) { fl |= 0x80000000u; c = rec_cap; }
-      acc += c;
-      const long long l = blk_lastp[b];
-      if (l > lp) lp = l;
-      fl |= blk_flags[b];
-    }
+    int acc = 0;
+#pragma unroll
+    for (int q = 0; q < kScanPer; ++q) acc += s_cnt[tid * kScanPer + q];
+    int total = 0;
+    int run = carry + block_excl_scan(acc, &total);            // (barriers inside)
+#pragma unroll
+    for (int q = 0; q < kScanPer; ++q) { const int c = s_cnt[tid * kScanPer + q]; s_cnt[tid * kScanPer + q] = run; run += c; }
+    __syncthreads();
+    for (int k = tid; k < kScanRound; k += kThreads)           // coalesced
+      if (base + k < nblk) blk_off[base + k] = s_cnt[k];
+    __syncthreads();
+    carry += total;
   }
   // workgroup reductions: max of lastp, OR of flags (wave shuffles, then 4 words)
 #pragma unroll
@@ -1055,26 +1061,13 @@ __global__ void __launch_bounds__(kThreads) k_scan(const int* blk_count, const l
     fl |= of;
   }
   if (lane == 0) { s_lp[wave] = lp; s_fl[wave] = fl; }
-  int total = 0;
-  int run = block_excl_scan(acc, &total);                      // contains the barriers that publish s_lp / s_fl
+  __syncthreads();
   if (tid == 0) {
     long long L = (*long_lastp == 0ull) ? kNoIndex : (long long)(*long_lastp) - (1ll << 62);
     unsigned F = 0;
     for (int w = 0; w < kWaves; ++w) { if (s_lp[w] > L) L = s_lp[w]; F |= s_fl[w]; }
-    sum->n_rec = total; sum->overflow = (F >> 31) & 1u; sum->flags = F & 0x7FFFFFFFu; sum->lastp = L;
+    sum->n_rec = carry; sum->overflow = (F >> 31) & 1u; sum->flags = F & 0x7FFFFFFFu; sum->lastp = L;
     sum->long_count = *long_count; sum->n_kept = 0; sum->last_kept_p = kNoIndex;
-  }
-  if (staged) {
-    for (int b = b0; b < b1; ++b) { const int c = s_cnt[b]; s_cnt[b] = run; run += c; }   // counts -> offsets, in LDS
-    __syncthreads();
-    for (int b = tid; b < nblk; b += kThreads) blk_off[b] = s_cnt[b];                       // coalesced
-  } else {
-    for (int b = b0; b < b1; ++b) {
-      int c = blk_count[b];
-      if (c > rec_cap) c = rec_cap;
-      blk_off[b] = run;
-      run += c;
-    }
   }
 }
 

@@ -174,3 +174,31 @@ def test_head_sync_predicts_fixup_and_fixup_is_exact(native):
         else:
             misses += 1
     assert hits > 100 and misses > 10
+
+
+def test_kernel_resources_keep_the_tail_co_resident():
+    """The pipelined pass rate depends on a resource fact, not only on code: k_detect launches exactly one resident round
+    of workgroups (5 per CU), and the sparse tail kernels of the PREVIOUS pass run beside it.  If they do not fit in
+    what five k_detect workgroups leave free on a CU, they run when k_detect drains and the next k_detect starts with
+    some of its workgroups in a second round (measured: 1.89 instead of 1.51 ms per pass when k_detect took 96 VGPRs).
+    The compiler's own report (written by gr_adsb_amd.build) is checked against those limits here."""
+    import json
+    from gr_adsb_amd import build as B
+    B.build()
+    res = json.load(open(B.RES))
+    LDS_CU, VGPR_SIMD, WG = 160 * 1024, 512, 5
+    alloc = lambda v: -(-v // 8) * 8                                    # noqa: E731  (allocation granule: 8 VGPRs)
+    detect = {k: v for k, v in res.items() if "k_detect" in k}
+    assert len(detect) == 5
+    tail = {k: v for k, v in res.items() if any(t in k for t in ("k_scan", "k_gather", "k_resolve", "k_count", "k_compact",
+                                                                    "k_publish", "k_longrun"))}
+    assert len(tail) >= 11
+    for name, d in detect.items():
+        assert d["scratch_bytes_per_lane"] == 0 and d["vgpr_spills"] == 0, name + ": spills in the streaming kernel"
+        assert d["occupancy_waves_per_simd"] >= WG, name
+        free_vgpr = VGPR_SIMD - WG * alloc(d["vgprs"])
+        free_lds = LDS_CU - WG * d["lds_bytes_per_block"]
+        for tname, t in tail.items():
+            assert alloc(t["vgprs"]) <= free_vgpr, "%s (%d VGPRs) does not fit beside %s (%d)" % (tname, t["vgprs"], name, d["vgprs"])
+            assert t["lds_bytes_per_block"] <= free_lds, "%s (%d B LDS) does not fit beside %s" % (tname, t["lds_bytes_per_block"], name)
+            assert t["scratch_bytes_per_lane"] == 0, tname

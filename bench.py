@@ -384,6 +384,8 @@ def main():
     ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--extra-min-time", type=float, default=0.25)
     ap.add_argument("--hostfed-log2n", type=int, default=26)
+    ap.add_argument("--depth", type=int, default=0, help="passes in flight (default: the library's ADSB_MAX_IN_FLIGHT)")
+    ap.add_argument("--low-latency", action="store_true", help="ADSB_FLAG_LOW_LATENCY: tail kernels beside the next pass's k_detect")
     ap.add_argument("--single-stream", action="store_true",
                     help="profiling aid (ADSB_FLAG_SINGLE_STREAM): the sparse tail of a pass behind its k_detect on one stream")
     ap.add_argument("--format", choices=["fc32", "sc16", "sc8", "cu8"], default="fc32",
@@ -423,7 +425,7 @@ def main():
     n_own = 1 << args.log2n
     stream_len = n_own * n_gpus
     fe = FrontEnd(fs, args.threshold, device=local_rank, timing=True,
-                  flags=_native.FLAG_SINGLE_STREAM if args.single_stream else 0)
+                  flags=(_native.FLAG_SINGLE_STREAM if args.single_stream else 0) | (_native.FLAG_LOW_LATENCY if args.low_latency else 0))
 
     intfmt = args.format != "fc32"
     fmt = {"fc32": _native.FMT_FC32, "sc16": _native.FMT_SC16, "sc8": _native.FMT_SC8, "cu8": _native.FMT_CU8}[args.format]
@@ -446,7 +448,7 @@ def main():
         iq = gen_stream_blocks(plan["hi"] - plan["lo"], plan["lo"], fs, args.bursts, args.seed, dev)
     torch.cuda.synchronize()
 
-    DEPTH = _native.MAX_IN_FLIGHT
+    DEPTH = min(args.depth, _native.MAX_IN_FLIGHT) if args.depth > 0 else _native.MAX_IN_FLIGHT
     pending = []          # tickets of submitted, not yet collected passes (pipeline of DEPTH passes)
     host_t = {"stitch": 0.0}
     stash = {}            # results of tickets that had to be collected early (fallback path only)
@@ -597,7 +599,7 @@ def main():
                             % (fs / 1e6, {"fc32": "complex64", "sc16": "int16", "sc8": "int8", "cu8": "uint8 offset-binary"}[args.format], args.bursts, args.threshold, args.log2n),
                 "fs": fs, "samples_per_gpu_per_step": n_own, "bursts_per_step_rank0": int(n_bursts),
                 "sharding": "none" if n_gpus == 1 else "%d overlapped time shards, host stitch" % n_gpus,
-                "pipeline": "%d passes in flight (submit/wait)%s" % (DEPTH, ", single stream" if args.single_stream else ""),
+                "pipeline": "%d passes in flight (submit/wait)%s" % (DEPTH, (", single stream" if args.single_stream else "") + (", low-latency tail" if args.low_latency else "")),
                 "detect_gap_ms_avg": round(st["detect_gap_ms"] / max(1, st["detect_gaps"]), 4),
                 "detect_grid": int(st["detect_grid"]), "retries": int(st["retries"]), "longrun_calls": int(st["longrun_calls"]),
                 "env": env_known,

@@ -1010,11 +1010,14 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total) {
 // LDS round by round (kScanRound lists each), the per-thread contiguous ranges of the prefix sum are walked there,
 // and the offsets go back through LDS the same way.  (A version whose threads read their 20 contiguous lists straight
 // from global memory -- 64 different cache lines per wave instruction -- was measured to lengthen the CONCURRENT
-// k_detect of the next pass by 0.03 ms; the same kernel with coalesced accesses costs it nothing.)  4 KB of LDS and
-// few registers on purpose: this workgroup must fit on a CU BESIDE five resident k_detect workgroups (7 KB of LDS and
-// 112 VGPRs per SIMD are free there), or the whole tail of a pass waits for the next pass's k_detect to drain.
-constexpr int kScanRound = 1024;
-constexpr int kScanPer = kScanRound / kThreads;      // 4 consecutive lists per thread and round
+// k_detect of the next pass by 0.03 ms; the same kernel with coalesced accesses costs it nothing.)  2 KB of LDS and
+// few registers on purpose: this workgroup is meant to fit on a CU BESIDE five resident k_detect workgroups (which
+// leave 3.8 KB of LDS -- in whole 1280-byte allocation granules -- and 112 VGPRs per SIMD free).
+#ifndef ADSB_SCAN_ROUND
+#define ADSB_SCAN_ROUND 512
+#endif
+constexpr int kScanRound = ADSB_SCAN_ROUND;
+constexpr int kScanPer = kScanRound / kThreads;      // consecutive lists per thread and round
 __global__ void __launch_bounds__(kThreads) k_scan(const int* blk_count, const long long* blk_lastp,
                                                    const unsigned* blk_flags, int nblk, int rec_cap,
                                                    const int* long_count, const unsigned long long* long_lastp,

@@ -222,7 +222,14 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   }
   // no-op unless k_detect listed pulses longer than its LDS window
   ADSB_BY_MODE(pl.mode, launch_longrun, ts, a);
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(kThreads), 0, ts, (const int*)a.blk_count,
+  // Every tail kernel is small enough to run on a CU BESIDE five resident k_detect workgroups (tests/test_abi.py holds
+  // the limits).  Whether it should is a choice: beside the next pass's k_detect the tail finishes ~0.25 ms after its own
+  // k_detect (results one pass earlier, two passes in flight suffice) but costs that k_detect 1-2 % (measured 1.58 vs
+  // 1.56 ms per 2^30-sample pass); kept out -- k_scan, the first kernel of the chain, is launched with 8 KB of unused
+  // dynamic LDS, more than five k_detect workgroups leave free on a CU -- it runs when that k_detect drains.
+  // Throughput is the default, ADSB_FLAG_LOW_LATENCY selects the other.
+  const unsigned scan_pad = (c->flags & ADSB_FLAG_LOW_LATENCY) ? 0u : 8192u;
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(kThreads), scan_pad, ts, (const int*)a.blk_count,
                      (const long long*)a.blk_lastp, (const unsigned*)a.blk_flags, s.nlists, s.rec_cap,
                      (const int*)a.long_count, (const unsigned long long*)a.long_lastp, (int*)s.d_blk_off.p, &misc->sum);
   const int gg = s.nlists < 1024 ? s.nlists : 1024;

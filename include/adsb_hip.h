@@ -65,6 +65,10 @@ extern "C" {
 /* Run the sparse tail of a pass on the compute stream behind its k_detect instead of on a second stream beside the
  * next pass's k_detect (profiling aid: serial kernels; about 15 % less throughput with several calls in flight). */
 #define ADSB_FLAG_SINGLE_STREAM 8u
+/* Pipelined use (adsb_submit_*): let the sparse tail of a pass (ordering, gate, compaction of the burst records) run on
+ * the GPU BESIDE the next pass's streaming kernel instead of after it: results arrive about one pass earlier and two
+ * calls in flight suffice, for 1-2 % less throughput.  Default off = maximum throughput. */
+#define ADSB_FLAG_LOW_LATENCY 16u
 
 /* adsb_burst.flags */
 #define ADSB_BURST_DEMOD 1u /* eob inside the demod input: bits[] valid, a PDU is published (demod.py:82) */

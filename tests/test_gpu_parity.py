@@ -302,13 +302,17 @@ def test_device_resident_synthetic_vs_c_oracle(native, torch_mod, fs, bps, log2n
     assert np.array_equal(got2["offset"], got["offset"] + 123456789012)
 
 
-def test_submit_wait_pipeline_matches_blocking_calls(native, torch_mod):
-    """Several passes in flight (adsb_submit_* / adsb_wait) must deliver exactly what the blocking call does."""
+@pytest.mark.parametrize("mode", ["default", "low_latency", "single_stream"])
+def test_submit_wait_pipeline_matches_blocking_calls(native, torch_mod, mode):
+    """Several passes in flight (adsb_submit_* / adsb_wait) must deliver exactly what the blocking call does -- with the
+    tail of a pass kept behind the next pass's k_detect (default), beside it (ADSB_FLAG_LOW_LATENCY), or everything on
+    one stream (ADSB_FLAG_SINGLE_STREAM)."""
     from gr_adsb_amd import modulator as M
     n = 1 << 21
     iqs = [M.synth_iq(n, 2e6, 2000, seed) for seed in (11, 12, 13)]
     ts = [to_dev(torch_mod, iq) for iq in iqs]
-    ctx = native.Context(2e6, 0.01)
+    ctx = native.Context(2e6, 0.01, flags={"default": 0, "low_latency": native.FLAG_LOW_LATENCY,
+                                           "single_stream": native.FLAG_SINGLE_STREAM}[mode])
     want = [ctx.process_iq_device(t.data_ptr(), n, abs_offset=1000 * i) for i, t in enumerate(ts)]
     t0 = ctx.submit_iq_device(ts[0].data_ptr(), n, 0)
     t1 = ctx.submit_iq_device(ts[1].data_ptr(), n, 1000)

@@ -384,6 +384,8 @@ def main():
     ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--extra-min-time", type=float, default=0.25)
     ap.add_argument("--hostfed-log2n", type=int, default=26)
+    ap.add_argument("--mixed-df", action="store_true",
+                    help="BASELINE config 5's signal as the main workload: DF mix of docs/DF_histogram.txt, SNR 3-25 dB over noise 2e-3")
     ap.add_argument("--depth", type=int, default=0, help="passes in flight (default: the library's ADSB_MAX_IN_FLIGHT)")
     ap.add_argument("--low-latency", action="store_true", help="ADSB_FLAG_LOW_LATENCY: tail kernels beside the next pass's k_detect")
     ap.add_argument("--single-stream", action="store_true",
@@ -430,8 +432,9 @@ def main():
     intfmt = args.format != "fc32"
     fmt = {"fc32": _native.FMT_FC32, "sc16": _native.FMT_SC16, "sc8": _native.FMT_SC8, "cu8": _native.FMT_CU8}[args.format]
     assert not (intfmt and n_gpus > 1)
+    synth = dict(noise_power=2e-3, df_choices=DF_MIX[0], df_weights=DF_MIX[1], snr_db_range=(3.0, 25.0)) if args.mixed_df else {}
     if n_gpus == 1:
-        iq = gen_stream_blocks(n_own, 0, fs, args.bursts, args.seed, dev)
+        iq = gen_stream_blocks(n_own, 0, fs, args.bursts, args.seed, dev, **synth)
         plan = None
         # quantise the same stream to the integer wire format (full scale 4.0); the kernel converts with the same scale
         if fmt == _native.FMT_SC16:
@@ -445,7 +448,7 @@ def main():
             iq = torch.clamp(torch.floor(iq * (127.5 / 4.0) + 128.0), 0, 255).to(torch.uint8).contiguous()
     else:
         plan = shard_plan(stream_len, n_gpus, sps, align=n_own)[rank]
-        iq = gen_stream_blocks(plan["hi"] - plan["lo"], plan["lo"], fs, args.bursts, args.seed, dev)
+        iq = gen_stream_blocks(plan["hi"] - plan["lo"], plan["lo"], fs, args.bursts, args.seed, dev, **synth)
     torch.cuda.synchronize()
 
     DEPTH = min(args.depth, _native.MAX_IN_FLIGHT) if args.depth > 0 else _native.MAX_IN_FLIGHT
@@ -594,9 +597,11 @@ def main():
                        "ms_per_step_max": round(max(times) / args.steps * 1e3, 4),
                        "note": "each repeat = exactly `steps` steps between barrier+synchronize, max over ranks; value uses the median repeat"},
             "config": {
-                "workload": "synthetic %g Msps %s IQ, %g DF17-length bursts/s, AWGN 1e-3, threshold %g; "
+                "workload": "synthetic %g Msps %s IQ, %g %s bursts/s, %s, threshold %g; "
                             "2^%d samples per GPU per step resident in HBM; one canonical framer+demod pass"
-                            % (fs / 1e6, {"fc32": "complex64", "sc16": "int16", "sc8": "int8", "cu8": "uint8 offset-binary"}[args.format], args.bursts, args.threshold, args.log2n),
+                            % (fs / 1e6, {"fc32": "complex64", "sc16": "int16", "sc8": "int8", "cu8": "uint8 offset-binary"}[args.format], args.bursts,
+                               "mixed-DF (docs/DF_histogram.txt proportions, SNR 3-25 dB)" if args.mixed_df else "DF17-length",
+                               "AWGN 2e-3" if args.mixed_df else "AWGN 1e-3", args.threshold, args.log2n),
                 "fs": fs, "samples_per_gpu_per_step": n_own, "bursts_per_step_rank0": int(n_bursts),
                 "sharding": "none" if n_gpus == 1 else "%d overlapped time shards, host stitch" % n_gpus,
                 "pipeline": "%d passes in flight (submit/wait)%s" % (DEPTH, (", single stream" if args.single_stream else "") + (", low-latency tail" if args.low_latency else "")),

@@ -25,7 +25,8 @@
 // (marks a wavefront-uniform value so it lives in a scalar register), `adsb_readlane(int, lane)` and
 // `adsb_bitrep32(u32) -> u64` (every bit doubled: s_bitreplicate_b64_b32), `adsb_opaque(int)` (returns its argument
 // through an empty asm statement, so that nothing derived from it is treated as loop invariant) and
-// `adsb_ld_stream<Q>(const char*)` (one Q-sized load of streamed, single-use data): the
+// `adsb_ld_stream<Q>(const char*)` (one Q-sized load of streamed, single-use data), and the macro ADSB_LDS (the
+// address-space qualifier of workgroup-local memory, empty for the emulator): the
 // product translation unit adsb_hip.hip maps them to __builtin_amdgcn_wave_barrier() / _readfirstlane() /
 // _readlane(); tests/sim/sim_driver.cpp includes the test-only SIMT emulator instead, so the very same
 // kernels run on a machine without a GPU.
@@ -456,9 +457,24 @@ __device__ void burst_finish(const DetectArgs& a, const BurstFetch<MODE>& f, Rec
 struct WinArgs {
   const void* data; long long n, in0_base, dem_hi, origin; float scale; int sps;
 };
+// s_x_generic: the window as a generic pointer (what crosses a real call); it is cast back to the LDS address space at
+// once, so the reads are ds_read (ordered by lgkmcnt) and not flat loads -- a flat load counts on vmcnt, and waiting for
+// it would also wait for the prefetch of the next tile, which is older and still in flight.  For the same reason the
+// parity masks arrive in registers (pc: loaded once per kernel) instead of being fetched here.
+#ifndef ADSB_INLINE_RECORDS
+#define ADSB_INLINE_RECORDS 1
+#endif
+#if ADSB_INLINE_RECORDS
+#define ADSB_RECORD_FN __forceinline__
+#else
+#define ADSB_RECORD_FN __attribute__((noinline))
+#endif
 template <int MODE>
-__device__ __attribute__((noinline)) void burst_from_window(WinArgs a, const float* s_x, long long t0, int p,
-                                                            unsigned xflags, Rec* out, int lane) {
+__device__ ADSB_RECORD_FN void burst_from_window(WinArgs a, const float* s_x_generic, long long t0, int p,
+                                                 unsigned xflags, Rec* out, int lane, unsigned long long pc_m1,
+                                                 unsigned long long pc_m2) {
+  const ParityConsts pc{pc_m1, pc_m2};
+  const ADSB_LDS float* s_x = (const ADSB_LDS float*)s_x_generic;
   const int sps = a.sps, half = sps >> 1;
   const long long P = t0 + p;
   long long wlo = P - kNoise;                                // framer.py:156: in0[max(0, pulse_idx-100) : pulse_idx]
@@ -477,7 +493,6 @@ __device__ __attribute__((noinline)) void burst_from_window(WinArgs a, const flo
     x1 = smp(j0); x0 = smp(j0 + half);                       // demod.py:91
     if (lane < 48) { y1 = smp(j0 + 64 * sps); y0 = smp(j0 + 64 * sps + half); }
   }
-  const ParityConsts pc = parity_consts(lane);
   burst_reduce(a.origin + P, nwin, val0, val1, peak, v0, v1, dem, x1, x0, y1, y0, xflags, out, lane, pc);
 }
 
@@ -676,6 +691,7 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
   }
 
   const int lane_outer = lane;
+  const ParityConsts pc = parity_consts(lane);               // four registers for the whole kernel, see burst_from_window
   for (long long t0 = c0; t0 < c1; t0 += kWTile) {
     // The lane number through an opaque copy, renewed every tile: otherwise a dozen lane-derived addresses and masks
     // (64-bit offsets of the loads, LDS addresses, 64*j + lane ...) are hoisted out of this loop as loop-invariant
@@ -884,7 +900,7 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
           const bool lh = (e & 0x10000u) != 0;
           if (lane == 0) my_cands[slot] = cand_make(t0 + (long long)p, lh ? kLongHint : 0u);
           burst_from_window<MODE>(WinArgs{a.data, a.n, a.in0_base, a.dem_hi, a.origin, a.scale, a.sps}, s_x, t0, p,
-                                  lh ? kRecLongHint : 0u, my_recs + slot, lane);
+                                  lh ? kRecLongHint : 0u, my_recs + slot, lane, pc.m1, pc.m2);
         }
       }
       nrec += nm;

@@ -43,6 +43,8 @@ __device__ __forceinline__ Q adsb_ld_stream(const char* p) {
   return *reinterpret_cast<const Q*>(p);
 #endif
 }
+// workgroup-local (LDS) address space qualifier for pointers that crossed a function call as generic pointers
+#define ADSB_LDS __attribute__((address_space(3)))
 // bit i of x -> bits 2i and 2i+1 (scalar unit; the argument must be wave-uniform)
 __device__ __forceinline__ unsigned long long adsb_bitrep32(unsigned x) {
   unsigned long long r;

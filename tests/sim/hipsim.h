@@ -195,6 +195,7 @@ inline void adsb_wave_sync() {
 
 inline int adsb_uniform(int v) { return v; }
 inline int adsb_opaque(int v) { return v; }
+#define ADSB_LDS
 template <class Q> inline Q adsb_ld_stream(const char* p) { Q q; memcpy(&q, p, sizeof(Q)); return q; }
 inline int adsb_readlane(int v, int lane) { return hipsim_shfl_idx(v, lane); }
 inline unsigned long long adsb_bitrep32(unsigned x) {

@@ -1,0 +1,10 @@
+#!/bin/bash
+# SQ instruction mix per config
+export TMPDIR=/tmp
+ROOT=$(pwd)
+cd /tmp
+for cfg in "--log2n 28" "--fs 8e6 --bursts 6000 --log2n 28" "--mixed-df --log2n 28" "--fs 20e6 --log2n 28"; do
+  rm -rf /tmp/sqx
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace -f csv -d /tmp/sqx -o p -- python $ROOT/bench.py --no-cpu --no-extra --no-hostfed --steps 4 --warmup 1 --min-time 0 $cfg > /tmp/sqx.log 2>&1
+  echo "== $cfg"; python $ROOT/tools/pmc_summary.py $(find /tmp/sqx -name '*counter_collection.csv' | head -1) | grep -A4 "k_detect"
+done

@@ -819,27 +819,30 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
           const int p = (r + f) >> 1;                      // framer.py:113
           if (i == nr - 1) lp = p;                         // centres increase with i; only the last rise of
           else if (i == nr - 2) lp2 = p;                   // a tile can be left without a fall
-          unsigned chips = 0;
+          // 16-chip test as a chain of booleans: a per-lane boolean is a lane mask in scalar registers, so every chip
+          // costs one vector compare and one scalar AND (assembling a 16-bit chip word per lane cost three vector
+          // instructions per chip)
+          bool match = true;
           if (p + 15 * half < kWWin) {                // all 16 taps inside the LDS window: one LDS round trip
             const float* tp = s_x + p;
             float tap[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) tap[k] = tp[k * half];
             const float hp = __fmul_rn(tap[0], 0.5f);      // tap 0 IS in0[pulse_idx]; /2 is exact
-            // (assembled from the top bit down with shift-or: bit masks 1 << k as operands would cost one register
-            // each for k >= 7, hoisted out of the tile loop)
 #pragma unroll
-            for (int k = 15; k >= 0; --k) chips = (chips << 1) | (tap[k] > hp ? 1u : 0u);
+            for (int k = 0; k < 16; ++k) match = match & ((tap[k] > hp) == (((kTemplate >> k) & 1u) != 0u));   // framer.py:140-147
           } else {                                         // rare: taps past the window come from global memory
             const float hp = __fmul_rn(s_x[p], 0.5f);
+            unsigned chips = 0;
 #pragma unroll 1
             for (int k = 0; k < 16; ++k) {
               const int idx = p + k * half;
               const float v = (idx < kWWin) ? s_x[idx] : xg<MODE>(a.data, a.n, t0 + idx, a.scale);
               chips |= (v > hp ? 1u : 0u) << k;
             }
+            match = chips == kTemplate;
           }
-          if (chips == kTemplate) {
+          if (match) {
             res = 0x8000u | (unsigned)p;
             if (a.long_aware) {                              // first data bit (demod.py:87-95, k = 0): DF >= 16 = long reply
               const int i1 = p + 16 * half, i0 = i1 + half;

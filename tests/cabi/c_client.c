@@ -83,6 +83,48 @@ int main(int argc, char** argv) {
   if (rc != 0 || n2 != nwant || adsb_last_result(c, &last, &nlast) != 0 || nlast != nwant ||
       (nwant > 0 && memcmp(last, got, (size_t)nwant * sizeof(adsb_burst)) != 0)) bad = 1;
 
+  /* host-fed pipelined submission (examples/adsb_rx.py:113-126,180-196 topology): three chunks in flight from the
+   * page-locked buffer, collected in order, each equal to the blocking result shifted by its stream offset */
+  {
+    int32_t tk[3] = {-1, -1, -1};
+    for (int k = 0; k < 3 && !bad; ++k)
+      if (adsb_submit_format_host(c, ADSB_FMT_FC32, pinned, n, (int64_t)k * 1000, &tk[k]) != 0) bad = 1;
+    int32_t t4 = -1;
+    if (!bad && adsb_submit_format_host(c, ADSB_FMT_FC32, pinned, n, 0, &t4) != -EBUSY) bad = 1;   /* every slot in flight */
+    adsb_burst* got2 = (adsb_burst*)calloc((size_t)nwant + 1, sizeof(adsb_burst));
+    for (int k = 0; k < 3 && !bad; ++k) {
+      int32_t m = -1;
+      if (adsb_wait(c, tk[k], got2, nwant + 1, &m) != 0 || m != nwant) { bad = 1; break; }
+      for (int32_t i = 0; i < nwant && !bad; ++i)
+        bad = got2[i].offset != got[i].offset + (int64_t)k * 1000 || memcmp(got2[i].bits, got[i].bits, 14) ||
+              got2[i].flags != got[i].flags || memcmp(&got2[i].median, &got[i].median, 4);
+    }
+    free(got2);
+  }
+  /* opt-in confidence ratios (demod.py:97-101): a context without the flag refuses, one with it returns n x 112 floats
+   * whose sign test reproduces the hard bits (bit = bit1_amp > bit0_amp  <=>  ratio > 1 for positive amplitudes) */
+  {
+    const float* ratio = NULL;
+    int32_t nr = -1;
+    if (adsb_last_confidence(c, &ratio, &nr) != -EINVAL) bad = 1;
+    adsb_ctx* cc = NULL;
+    if (adsb_create(fs, thr, 0, ADSB_FLAG_CONFIDENCE, &cc) != 0) bad = 1;
+    else {
+      int32_t m = -1;
+      if (adsb_process_iq(cc, (const float*)pinned, n, 0, NULL, 0, &m) != 0 || m != nwant ||
+          adsb_last_confidence(cc, &ratio, &nr) != 0 || nr != nwant || (nwant > 0 && !ratio)) bad = 1;
+      for (int32_t i = 0; i < nwant && !bad; ++i) {
+        if (!(got[i].flags & ADSB_BURST_DEMOD)) continue;
+        for (int k = 0; k < 112 && !bad; ++k) {
+          const int bit = (got[i].bits[k >> 3] >> (7 - (k & 7))) & 1;
+          const float q = ratio[(size_t)i * 112 + k];
+          if (q == q && q != 1.0f && (q > 1.0f) != (bit != 0)) bad = 1;   /* NaN (0/0) and exact ties carry no sign */
+        }
+      }
+      adsb_destroy(cc);
+    }
+  }
+
   printf("%d bursts, %s\n", (int)n_out, bad ? "MISMATCH" : "identical");
   adsb_host_free(pinned);
   adsb_destroy(c);

@@ -275,6 +275,7 @@ def extra_configs(args, dev, depth):
                "fs": fs, "value": round(n / ms / 1e3, 1), "unit": "Msamples/s", "ms_per_step": round(ms, 4),
                "steps": args.extra_steps, "repeats": len(times), "bursts_per_step": int(nb),
                "longrun_calls": int(st["longrun_calls"]), "retries": int(st["retries"]),
+               "long_pulses_per_step": round(st["longrun_pulses"] / max(1, st["calls"]), 2),
                "roofline": roofline_of(st, "fc32", iso_ms)}
         # parity: the GPU pass over the first 2^26 samples against the scalar C port of the reference path
         host = iq[:cpu_n].cpu().numpy().view(np.complex64).reshape(-1)
@@ -607,6 +608,7 @@ def main():
                 "pipeline": "%d passes in flight (submit/wait)%s" % (DEPTH, (", single stream" if args.single_stream else "") + (", low-latency tail" if args.low_latency else "")),
                 "detect_gap_ms_avg": round(st["detect_gap_ms"] / max(1, st["detect_gaps"]), 4),
                 "detect_grid": int(st["detect_grid"]), "retries": int(st["retries"]), "longrun_calls": int(st["longrun_calls"]),
+                "long_pulses_per_step": round(st["longrun_pulses"] / max(1, st["calls"]), 2),
                 "env": env_known,
             },
             "roofline": roofline_of(st, args.format, iso_ms),

@@ -50,7 +50,7 @@ class Stats(ctypes.Structure):
     _fields_ = [("detect_launches", ctypes.c_uint64), ("detect_ms", ctypes.c_double), ("detect_samples", ctypes.c_uint64),
                 ("detect_bytes", ctypes.c_uint64), ("calls", ctypes.c_uint64), ("retries", ctypes.c_uint64),
                 ("longrun_calls", ctypes.c_uint64), ("detect_grid", ctypes.c_uint64), ("blocks_per_cu", ctypes.c_uint64),
-                ("detect_gap_ms", ctypes.c_double), ("detect_gaps", ctypes.c_uint64)]
+                ("detect_gap_ms", ctypes.c_double), ("detect_gaps", ctypes.c_uint64), ("longrun_pulses", ctypes.c_uint64)]
 
 
 class AdsbError(RuntimeError):

@@ -357,7 +357,7 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
       c->stats.calls--;
       continue;
     }
-    if (s.h_sum->long_count > 0) c->stats.longrun_calls++;
+    if (s.h_sum->long_count > 0) { c->stats.longrun_calls++; c->stats.longrun_pulses += (uint64_t)s.h_sum->long_count; }
     if (s.h_sum->long_count > s.args.long_cap) { s.busy = false; return fail(c, -EIO, "long-rise list overflow"); }
     *sum = *s.h_sum;
     const int nres = sum->n_kept;

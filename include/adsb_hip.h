@@ -109,6 +109,7 @@ typedef struct adsb_stats {
   uint64_t blocks_per_cu;    /* resident k_detect workgroups per CU (occupancy query) */
   double detect_gap_ms;      /* sum of idle gaps on the compute stream between consecutive timed k_detect launches */
   uint64_t detect_gaps;      /* number of gaps summed */
+  uint64_t longrun_pulses;   /* pulses longer than k_detect's LDS window, handled by the long-pulse kernel (sum over calls) */
 } adsb_stats;
 
 int adsb_abi_version(void);

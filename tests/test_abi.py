@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(native):
 def test_struct_layouts(native):
     assert native.BURST_DTYPE.itemsize == 32
     assert native.BURST_DTYPE.fields["bits"][1] == 16 and native.BURST_DTYPE.fields["flags"][1] == 30
-    assert ctypes.sizeof(native.Stats) == 88
+    assert ctypes.sizeof(native.Stats) == 96
 
 
 def test_no_cpu_fallback_without_device(native):

@@ -488,10 +488,16 @@ __device__ ADSB_RECORD_FN void burst_from_window(WinArgs a, const float* s_x_gen
   const bool dem = P + 119ll * sps + half < a.dem_hi;        // demod.py:76,82 (sps even)
   float x1 = 0.0f, x0 = 0.0f, y1 = 0.0f, y0 = 0.0f;
   if (dem) {                                                 // wave-uniform
-    auto smp = [&](int j) -> float { return (j < kWWin) ? s_x[j] : xg<MODE>(a.data, a.n, t0 + j, a.scale); };
     const int j0 = p + 8 * sps + lane * sps;                 // demod.py:75,87
-    x1 = smp(j0); x0 = smp(j0 + half);                       // demod.py:91
-    if (lane < 48) { y1 = smp(j0 + 64 * sps); y0 = smp(j0 + 64 * sps + half); }
+    if (p + 119 * sps + half < kWWin) {
+      // wave-uniform fast path (every 2 Msps burst that starts in the tile): all 224 bit samples lie in the LDS window
+      x1 = s_x[j0]; x0 = s_x[j0 + half];                     // demod.py:91
+      if (lane < 48) { y1 = s_x[j0 + 64 * sps]; y0 = s_x[j0 + 64 * sps + half]; }
+    } else {
+      auto smp = [&](int j) -> float { return (j < kWWin) ? s_x[j] : xg<MODE>(a.data, a.n, t0 + j, a.scale); };
+      x1 = smp(j0); x0 = smp(j0 + half);
+      if (lane < 48) { y1 = smp(j0 + 64 * sps); y0 = smp(j0 + 64 * sps + half); }
+    }
   }
   burst_reduce(a.origin + P, nwin, val0, val1, peak, v0, v1, dem, x1, x0, y1, y0, xflags, out, lane, pc);
 }

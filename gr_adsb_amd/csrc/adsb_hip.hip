@@ -90,6 +90,7 @@ struct Slot {
   size_t h_ratio_cap = 0;
   hipEvent_t done = nullptr, ev0 = nullptr, ev1 = nullptr, det_done = nullptr, h2d_done = nullptr;
   bool busy = false;
+  bool direct = false;           // small pass: k_compact writes the records straight into h_out (no device->host copy)
   bool is_shard = false;
   bool ev1_valid = false;
   Plan plan{};
@@ -121,7 +122,7 @@ struct adsb_ctx {
   Slot slot[ADSB_MAX_IN_FLIGHT];
   int next_slot = 0;
   int last_slot = 0;
-  DevBuf d_in, d_tags, d_bits, d_ok, d_ratio;
+  DevBuf d_in;            // device copy of the host input of the blocking entry points
   int rec_cap_shift = 0;  // rec_cap multiplier (grows on overflow)
   void* h_stage = nullptr;   // pinned staging for pageable inputs of the blocking entry points
   size_t h_stage_cap = 0;
@@ -249,8 +250,8 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted,
                      (const Summary*)&misc->sum, fmask, fwant, pl.head_n, (int*)s.d_seg.p);
   hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted, (const Rec*)sorted_recs,
-                     &misc->sum, (const int*)s.d_seg.p, fmask, fwant, pl.head_n, (Rec*)s.d_out.p, (int)s.tot, a.long_count,
-                     a.long_lastp);
+                     &misc->sum, (const int*)s.d_seg.p, fmask, fwant, pl.head_n, (Rec*)(s.direct ? s.h_out : s.d_out.p), (int)s.tot,
+                     a.long_count, a.long_lastp);
   // the summary goes straight into s.h_sum (pinned host memory, device-visible): visible to the host once the `done`
   // event below has completed
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ts, (const Summary*)&misc->sum, s.h_sum);
@@ -286,7 +287,13 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   if ((r = ensure(c, s.d_recs, (size_t)s.tot * sizeof(Rec)))) return r;
   if ((r = ensure(c, s.d_sorted, (size_t)s.tot * 8))) return r;
   if ((r = ensure(c, s.d_sorted_recs, (size_t)s.tot * sizeof(Rec)))) return r;
-  if ((r = ensure(c, s.d_out, (size_t)s.tot * sizeof(Rec)))) return r;
+  // A pass that can deliver only a few records (the GNU Radio work() calls: a few thousand samples) writes them from
+  // k_compact straight into the pinned, device-visible result buffer: no device->host copy and no second
+  // synchronisation at adsb_wait (the 48-byte summary travels the same way); bulk passes keep the DMA copy.
+  const long long kDirectRecs = tune_int("ADSB_TUNE_DIRECT_RECS", 16384);
+  s.direct = s.tot <= kDirectRecs;
+  if (s.direct) { if ((r = ensure_pinned(c, s.h_out, s.h_out_cap, (size_t)s.tot * sizeof(Rec)))) return r; }
+  else if ((r = ensure(c, s.d_out, (size_t)s.tot * sizeof(Rec)))) return r;
   if ((r = ensure(c, s.d_seg, (size_t)(s.tot / kThreads + 2) * sizeof(int)))) return r;
   if ((r = ensure(c, s.d_blk_count, (size_t)nlists * sizeof(int)))) return r;
   if ((r = ensure(c, s.d_blk_lastp, (size_t)nlists * sizeof(long long)))) return r;
@@ -361,10 +368,12 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
     if (s.h_sum->long_count > s.args.long_cap) { s.busy = false; return fail(c, -EIO, "long-rise list overflow"); }
     *sum = *s.h_sum;
     const int nres = sum->n_kept;
-    int r = ensure_pinned(c, s.h_out, s.h_out_cap, (size_t)(nres > 0 ? nres : 1) * sizeof(Rec));
+    int r = s.direct ? 0 : ensure_pinned(c, s.h_out, s.h_out_cap, (size_t)(nres > 0 ? nres : 1) * sizeof(Rec));
     if (r) { s.busy = false; return r; }
-    if (nres > 0) {
-      HIPCHK(c, hipMemcpyAsync(s.h_out, s.d_out.p, (size_t)nres * sizeof(Rec), hipMemcpyDeviceToHost, c->copy_stream));
+    const Rec* recs_dev = (const Rec*)(s.direct ? s.h_out : s.d_out.p);
+    if (nres > 0 && (!s.direct || (c->flags & ADSB_FLAG_CONFIDENCE))) {
+      if (!s.direct)
+        HIPCHK(c, hipMemcpyAsync(s.h_out, s.d_out.p, (size_t)nres * sizeof(Rec), hipMemcpyDeviceToHost, c->copy_stream));
       if (c->flags & ADSB_FLAG_CONFIDENCE) {
         // opt-in (demod.py:97-101): bit1/bit0 ratios of the delivered records, computed now that their number is
         // known -- one more small kernel and copy on the copy stream, paid only by callers who ask for it
@@ -373,7 +382,7 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
         HIPCHK(c, hipMemsetAsync(s.d_ratio.p, 0, rb, c->copy_stream));
         int cg = (nres + kWaves - 1) / kWaves;
         if (cg > c->n_cu * 8) cg = c->n_cu * 8;
-        ADSB_BY_MODE(s.plan.mode, launch_confidence, c->copy_stream, cg, s.args, (const Rec*)s.d_out.p,
+        ADSB_BY_MODE(s.plan.mode, launch_confidence, c->copy_stream, cg, s.args, recs_dev,
                      (const Summary*)&((Misc*)s.d_misc.p)->sum, nres, (float*)s.d_ratio.p);
         HIPCHK(c, hipMemcpyAsync(s.h_ratio, s.d_ratio.p, rb, hipMemcpyDeviceToHost, c->copy_stream));
       }
@@ -428,17 +437,26 @@ bool is_pinned_host(const void* p) {
   return at.type == hipMemoryTypeHost;
 }
 
-// Host buffer -> device staging buffer.  Pinned sources (adsb_host_alloc, hipHostMalloc, torch pin_memory)
-// go straight over PCIe; pageable ones are first copied into the context's pinned staging buffer.
+// Host buffer -> something the kernels can read, for the blocking entry points (the buffer only has to stay valid until
+// the call returns).  Large inputs are copied to the device: page-locked sources (adsb_host_alloc, hipHostMalloc, torch
+// pin_memory) go straight over PCIe, pageable ones through the context's pinned staging buffer.  Small inputs (the GNU
+// Radio work() calls: a few thousand samples) are not copied to the device at all: the kernels read the page-locked
+// copy in place over PCIe, once -- one operation fewer in a call whose cost is operations, not bytes.
 int upload(adsb_ctx* c, const void* host, size_t bytes, void** d_out) {
+  const size_t kZeroCopyBytes = (size_t)tune_int("ADSB_TUNE_ZERO_COPY_BYTES", 256 << 10);
   int rc;
-  if ((rc = ensure(c, c->d_in, bytes + 64))) return rc;
   const void* src = host;
-  if (!is_pinned_host(host)) {
+  const bool pinned = is_pinned_host(host);
+  if (!pinned || (bytes <= kZeroCopyBytes && ((uintptr_t)host & 15u) != 0)) {
     if ((rc = ensure_pinned(c, c->h_stage, c->h_stage_cap, bytes))) return rc;
     memcpy(c->h_stage, host, bytes);
     src = c->h_stage;
   }
+  if (bytes <= kZeroCopyBytes) {
+    *d_out = const_cast<void*>(src);
+    return 0;
+  }
+  if ((rc = ensure(c, c->d_in, bytes + 64))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->d_in.p, src, bytes, hipMemcpyHostToDevice, c->stream));
   *d_out = c->d_in.p;
   return 0;
@@ -523,7 +541,7 @@ void adsb_destroy(adsb_ctx* c) {
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   if (c->h2d_stream) (void)hipStreamSynchronize(c->h2d_stream);
   if (c->tail_stream) (void)hipStreamSynchronize(c->tail_stream);
-  DevBuf* bufs[] = {&c->d_in, &c->d_tags, &c->d_bits, &c->d_ok, &c->d_ratio};
+  DevBuf* bufs[] = {&c->d_in};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (Slot& sl : c->slot) {
     DevBuf* sb[] = {&sl.d_cands, &sl.d_recs, &sl.d_sorted, &sl.d_sorted_recs, &sl.d_out, &sl.d_seg, &sl.d_blk_count,
@@ -769,17 +787,15 @@ int adsb_demod_work(adsb_ctx* c, const float* in0, int64_t n, int64_t nitems_rea
   if (ntags == 0) return 0;
   HIPCHK(c, hipSetDevice(c->device));
   // (independent of submitted calls still in flight: own buffers, ordered behind them on the compute stream)
-  // every buffer is acquired BEFORE anything is queued, so no error path leaves work in flight; all transfers go
-  // through the context's pinned scratch (layout: tag positions | packed bits | ok | ratios) and ONE synchronisation
+  // Tag positions, packed bits, ok flags and ratios live in the context's pinned, device-visible scratch (layout: tag
+  // positions | packed bits | ok | ratios): the kernel reads and writes them in place, so the call is one sample upload,
+  // one kernel and ONE synchronisation.  Every buffer is acquired BEFORE anything is queued: no error path leaves work
+  // in flight.
   const size_t nt = (size_t)ntags;
   const size_t o_bits = nt * 8, o_ok = o_bits + nt * 14, o_ratio = (o_ok + nt + 15) & ~(size_t)15;
   const size_t total = o_ratio + (ratio ? nt * 112 * sizeof(float) : 0);
   int rc;
   if ((rc = ensure_pinned(c, c->h_dm, c->h_dm_cap, total))) return rc;
-  if ((rc = ensure(c, c->d_tags, nt * 8))) return rc;
-  if ((rc = ensure(c, c->d_bits, nt * 14))) return rc;
-  if ((rc = ensure(c, c->d_ok, nt))) return rc;
-  if (ratio && (rc = ensure(c, c->d_ratio, nt * 112 * sizeof(float)))) return rc;
   char* h = (char*)c->h_dm;
   long long* loc = (long long*)h;
   // local positions of the tags inside in0 (demod.py:79: offset - nitems_written); a tag outside the chunk -- the
@@ -787,26 +803,23 @@ int adsb_demod_work(adsb_ctx* c, const float* in0, int64_t n, int64_t nitems_rea
   for (int t = 0; t < ntags; ++t) loc[t] = tag_offsets[t] - nitems_read;
   void* d = nullptr;
   if ((rc = upload(c, in0, (size_t)n * 4, &d))) return rc;
-  hipError_t he = hipMemcpyAsync(c->d_tags.p, loc, nt * 8, hipMemcpyHostToDevice, c->stream);
-  if (he == hipSuccess) {
-    int nb = (ntags + kWaves - 1) / kWaves;
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL((k_slice<1>), dim3(nb), dim3(kThreads), 0, c->stream, (const void*)d, (long long)n,
-                       (const long long*)c->d_tags.p, (int)ntags, c->sps, (unsigned char*)c->d_bits.p,
-                       (unsigned char*)c->d_ok.p, ratio ? (float*)c->d_ratio.p : (float*)nullptr);
-    he = hipMemcpyAsync(h + o_bits, c->d_bits.p, nt * 14, hipMemcpyDeviceToHost, c->stream);
-  }
-  if (he == hipSuccess) he = hipMemcpyAsync(h + o_ok, c->d_ok.p, nt, hipMemcpyDeviceToHost, c->stream);
-  if (he == hipSuccess && ratio) he = hipMemcpyAsync(h + o_ratio, c->d_ratio.p, nt * 112 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-  const hipError_t hs = hipStreamSynchronize(c->stream);       // always: nothing stays queued behind an error return
-  if (he == hipSuccess) he = hs;
+  int nb = (ntags + kWaves - 1) / kWaves;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL((k_slice<1>), dim3(nb), dim3(kThreads), 0, c->stream, (const void*)d, (long long)n,
+                     (const long long*)loc, (int)ntags, c->sps, (unsigned char*)(h + o_bits),
+                     (unsigned char*)(h + o_ok), ratio ? (float*)(h + o_ratio) : (float*)nullptr);
+  hipError_t he = hipStreamSynchronize(c->stream);            // always: nothing stays queued behind an error return
   if (he == hipSuccess) he = hipGetLastError();
   if (he != hipSuccess) return fail(c, -EIO, "k_slice", he);
   const unsigned char* packed = (const unsigned char*)(h + o_bits);
   for (size_t t = 0; t < nt; ++t)
     for (int k = 0; k < 112; ++k) bits112[t * 112 + k] = (packed[t * 14 + (k >> 3)] >> (7 - (k & 7))) & 1u;
   memcpy(ok, h + o_ok, nt);
-  if (ratio) memcpy(ratio, h + o_ratio, nt * 112 * sizeof(float));
+  if (ratio) {
+    memcpy(ratio, h + o_ratio, nt * 112 * sizeof(float));
+    for (size_t t = 0; t < nt; ++t)                            // the kernel leaves the rows of dropped tags untouched
+      if (!ok[t]) memset(ratio + t * 112, 0, 112 * sizeof(float));
+  }
   return 0;
 }
 

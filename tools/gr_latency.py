@@ -16,16 +16,28 @@ for N in (2048, 8192, 32768, 262144):
     fr = blocks.framer(fs, 0.01)
     dm = blocks.demod(fs)
     out = np.empty(N, np.float32)
-    pos, calls = 0, 0
-    t0 = time.perf_counter()
-    while pos + N <= len(x):
-        fr._nread = fr._nwritten = pos
-        fr.work([buf[pos:pos + N + H - 1]], [out])
-        dm.tags_in = fr.tags_out[-64:]
-        dm._nread = dm._nwritten = pos
-        dm.work([x[pos:pos + N]], [out])
-        pos += N
-        calls += 1
-    dt = time.perf_counter() - t0
-    print("chunk %7d samples: %.3f ms per framer+demod call pair -> %.1f Msamples/s sustained (%d tags, %d PDUs)"
-          % (N, dt / calls * 1e3, pos / dt / 1e6, len(fr.tags_out), len(dm.messages)))
+    tf = td = 0.0
+    calls = samples = 0
+    for rep in range(-1, max(1, 64 * N // len(x))):           # rep -1: untimed warm-up (allocations of a fresh context)
+        pos = 0
+        while pos + N <= len(x):
+            fr._nread = fr._nwritten = pos
+            t1 = time.perf_counter()
+            fr.work([buf[pos:pos + N + H - 1]], [out])
+            t2 = time.perf_counter()
+            dm.tags_in = [t for t in fr.tags_out[-256:] if t.offset >= pos]       # the tags of this chunk
+            dm._nread = dm._nwritten = pos
+            dm.work([x[pos:pos + N]], [out])
+            t3 = time.perf_counter()
+            pos += N
+            if rep >= 0:
+                tf += t2 - t1
+                td += t3 - t2
+                calls += 1
+                samples += N
+            elif pos >= 4 * N:
+                break
+        fr.tags_out.clear()
+        dm.messages.clear()
+    print("chunk %7d samples: %.3f ms per framer+demod call pair (framer %.3f, demod %.3f; %d pairs) -> %.1f Msamples/s sustained"
+          % (N, (tf + td) / calls * 1e3, tf / calls * 1e3, td / calls * 1e3, calls, samples / (tf + td) / 1e6))

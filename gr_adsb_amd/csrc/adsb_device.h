@@ -951,12 +951,12 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
 // with global-memory taps and overwrites the placeholder.  Rare (CW / overload, or dense overlapping
 // bursts): it is launched after every k_detect and returns at once when the list is empty.
 template <int MODE>
-__global__ void __launch_bounds__(kThreads) k_longrun(DetectArgs a) {
+__device__ __forceinline__ void longrun_body(int bid, int nb, const DetectArgs& a) {
   __shared__ unsigned long long s_found;   // fall index relative to rise+1
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int n_entries = *a.long_count;                 // written by k_detect, usually 0: then this kernel is a no-op
+  int n_entries = *a.long_count;                 // written by k_detect, usually 0: then this is a no-op
   if (n_entries > a.long_cap) n_entries = a.long_cap;
-  for (int e = blockIdx.x; e < n_entries; e += gridDim.x) {
+  for (int e = bid; e < n_entries; e += nb) {
     const LongRise le = a.longlist[e];
     const long long limit = a.fall_hi;
     const long long start = le.rise + 1;
@@ -1004,6 +1004,10 @@ __global__ void __launch_bounds__(kThreads) k_longrun(DetectArgs a) {
     __syncthreads();
   }
 }
+template <int MODE>
+__global__ void __launch_bounds__(kThreads) k_longrun(DetectArgs a) {
+  longrun_body<MODE>((int)blockIdx.x, (int)gridDim.x, a);
+}
 
 // Exclusive prefix sum of one int per thread over a 256-thread workgroup (wave shuffles + 4 LDS words).
 // Every thread must call it; *total receives the sum on every thread.
@@ -1043,10 +1047,10 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total) {
 #endif
 constexpr int kScanRound = ADSB_SCAN_ROUND;
 constexpr int kScanPer = kScanRound / kThreads;      // consecutive lists per thread and round
-__global__ void __launch_bounds__(kThreads) k_scan(const int* blk_count, const long long* blk_lastp,
-                                                   const unsigned* blk_flags, int nblk, int rec_cap,
-                                                   const int* long_count, const unsigned long long* long_lastp,
-                                                   int* blk_off, Summary* sum) {
+__device__ __forceinline__ void scan_body(const int* blk_count, const long long* blk_lastp,
+                                          const unsigned* blk_flags, int nblk, int rec_cap,
+                                          const int* long_count, const unsigned long long* long_lastp,
+                                          int* blk_off, Summary* sum) {
   __shared__ long long s_lp[kWaves];
   __shared__ unsigned s_fl[kWaves];
   __shared__ int s_cnt[kScanRound];
@@ -1098,12 +1102,20 @@ __global__ void __launch_bounds__(kThreads) k_scan(const int* blk_count, const l
     sum->long_count = *long_count; sum->n_kept = 0; sum->last_kept_p = kNoIndex;
   }
 }
+__global__ void __launch_bounds__(kThreads) k_scan(const int* blk_count, const long long* blk_lastp,
+                                                   const unsigned* blk_flags, int nblk, int rec_cap,
+                                                   const int* long_count, const unsigned long long* long_lastp,
+                                                   int* blk_off, Summary* sum) {
+  scan_body(blk_count, blk_lastp, blk_flags, nblk, rec_cap, long_count, long_lastp, blk_off, sum);
+}
 
 // ---- k_gather: per-unit lists (centre words + burst records) -> one list each in stream order --------
-__global__ void __launch_bounds__(kThreads) k_gather(const unsigned long long* cands, const Rec* recs, const int* blk_count,
-                                                     const int* blk_off, int nblk, int rec_cap,
-                                                     unsigned long long* sorted, Rec* sorted_recs) {
-  for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+// (the tail kernels are bodies with the workgroup's index and the grid size as parameters: k_tail_small runs them all
+// in ONE workgroup for small passes)
+__device__ __forceinline__ void gather_body(int bid, int nb, const unsigned long long* cands, const Rec* recs,
+                                            const int* blk_count, const int* blk_off, int nblk, int rec_cap,
+                                            unsigned long long* sorted, Rec* sorted_recs) {
+  for (int b = bid; b < nblk; b += nb) {
     int c = blk_count[b];
     if (c > rec_cap) c = rec_cap;
     const int off = blk_off[b];
@@ -1115,19 +1127,24 @@ __global__ void __launch_bounds__(kThreads) k_gather(const unsigned long long* c
     for (int j = threadIdx.x; j < 2 * c; j += kThreads) rd[j] = rs[j];
   }
 }
+__global__ void __launch_bounds__(kThreads) k_gather(const unsigned long long* cands, const Rec* recs, const int* blk_count,
+                                                     const int* blk_off, int nblk, int rec_cap,
+                                                     unsigned long long* sorted, Rec* sorted_recs) {
+  gather_body((int)blockIdx.x, (int)gridDim.x, cands, recs, blk_count, blk_off, nblk, rec_cap, sorted, sorted_recs);
+}
 
 // ---- k_resolve: the re-trigger gate (framer.py:121-123,165) as parallel chain walks -----------------
 // Sequentially: accept a matched centre p iff p > eob, then eob = p + 63*sps.  A centre more than
 // 63*sps past its predecessor is accepted whatever happened before it, so it starts an independent
 // chain; each chain head walks its own (short) chain.  Words flagged kNoMatch are skipped.
-__global__ void __launch_bounds__(kThreads) k_resolve(unsigned long long* sorted, const Summary* sum, long long gate,
-                                                      long long gate_long, long long prev_eob) {
+__device__ __forceinline__ void resolve_body(int bid, int nb, unsigned long long* sorted, const Summary* sum, long long gate,
+                                             long long gate_long, long long prev_eob) {
   // gate = 63*sps; gate_long = what a centre flagged kLongHint holds the gate for (119*sps with the long-aware gate,
   // else == gate: flags are never set then); prev_eob = carried eob as a local index (or very negative).
   // Chain heads are found with the LARGER window, which is always safe.
   const int n = sum->n_rec;
   const int nseg = (n + kThreads - 1) / kThreads;
-  for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+  for (int seg = bid; seg < nseg; seg += nb) {
     const int i = seg * kThreads + threadIdx.x;
     if (i < n && !(cand_flags(sorted[i]) & kNoMatch)) {
       const long long p = cand_p(sorted[i]);
@@ -1158,6 +1175,10 @@ __global__ void __launch_bounds__(kThreads) k_resolve(unsigned long long* sorted
     }
   }
 }
+__global__ void __launch_bounds__(kThreads) k_resolve(unsigned long long* sorted, const Summary* sum, long long gate,
+                                                      long long gate_long, long long prev_eob) {
+  resolve_body((int)blockIdx.x, (int)gridDim.x, sorted, sum, gate, gate_long, prev_eob);
+}
 
 // ---- k_count / k_compact: survivors -> dense list ---------------------------------------------------
 // A real centre survives when (flags & fmask) == fwant -- gate on: (kKept, kKept); gate off: (0, 0) -- or
@@ -1169,13 +1190,13 @@ __device__ __forceinline__ bool survives(unsigned long long c, int i, unsigned f
   return (f & fmask) == fwant || i < head_n;
 }
 
-__global__ void __launch_bounds__(kThreads) k_count(const unsigned long long* sorted, const Summary* sum,
-                                                    unsigned fmask, unsigned fwant, int head_n, int* seg_count) {
+__device__ __forceinline__ void count_body(int bid, int nb, const unsigned long long* sorted, const Summary* sum,
+                                           unsigned fmask, unsigned fwant, int head_n, int* seg_count) {
   __shared__ int s_c[kWaves];
   const int n = sum->n_rec;
   const int nseg = (n + kThreads - 1) / kThreads;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+  for (int seg = bid; seg < nseg; seg += nb) {
     const int i = seg * kThreads + threadIdx.x;
     const bool kept = i < n && survives(sorted[i], i, fmask, fwant, head_n);
     const unsigned long long m = __ballot(kept);
@@ -1185,25 +1206,28 @@ __global__ void __launch_bounds__(kThreads) k_count(const unsigned long long* so
     __syncthreads();
   }
 }
+__global__ void __launch_bounds__(kThreads) k_count(const unsigned long long* sorted, const Summary* sum,
+                                                    unsigned fmask, unsigned fwant, int head_n, int* seg_count) {
+  count_body((int)blockIdx.x, (int)gridDim.x, sorted, sum, fmask, fwant, head_n, seg_count);
+}
 
 // k_compact also does what a separate single-workgroup scan kernel used to: every workgroup sums the segment counts
 // in front of its segment itself (a few hundred ints, L2 resident) -- one launch fewer on the tail of every pass.
 // Emits the survivors' burst records (built by k_detect / k_longrun, ordered by k_gather) with kKept / kHead added.
-__global__ void __launch_bounds__(kThreads) k_compact(const unsigned long long* sorted, const Rec* sorted_recs, Summary* sum,
-                                                      const int* seg_count, unsigned fmask, unsigned fwant, int head_n,
-                                                      Rec* out, int out_cap, int* long_count,
-                                                      unsigned long long* long_lastp) {
+__device__ __forceinline__ void compact_body(int bid, int nb, const unsigned long long* sorted, const Rec* sorted_recs,
+                                             Summary* sum, const int* seg_count, unsigned fmask, unsigned fwant, int head_n,
+                                             Rec* out, int out_cap, int* long_count, unsigned long long* long_lastp) {
   __shared__ int s_c[kWaves];
   __shared__ int s_pre[kWaves], s_tot[kWaves];
   const int n = sum->n_rec;
   const int nseg = (n + kThreads - 1) / kThreads;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (bid == 0 && threadIdx.x == 0) {
     *long_count = 0;        // k_scan has consumed the long-pulse list: leave it empty for the slot's next pass
     *long_lastp = 0ull;
     if (nseg == 0) sum->n_kept = 0;
   }
-  for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+  for (int seg = bid; seg < nseg; seg += nb) {
     // exclusive prefix of this segment and the grand total
     int pre = 0, tot = 0;
     for (int j = threadIdx.x; j < nseg; j += kThreads) {
@@ -1234,11 +1258,51 @@ __global__ void __launch_bounds__(kThreads) k_compact(const unsigned long long* 
     __syncthreads();
   }
 }
+__global__ void __launch_bounds__(kThreads) k_compact(const unsigned long long* sorted, const Rec* sorted_recs, Summary* sum,
+                                                      const int* seg_count, unsigned fmask, unsigned fwant, int head_n,
+                                                      Rec* out, int out_cap, int* long_count,
+                                                      unsigned long long* long_lastp) {
+  compact_body((int)blockIdx.x, (int)gridDim.x, sorted, sorted_recs, sum, seg_count, fmask, fwant, head_n, out, out_cap,
+               long_count, long_lastp);
+}
 
 // ---- k_publish: the pass's 48-byte summary, final once k_compact is done, stored straight into the caller-visible
 // (pinned, mapped) host copy -- no separate copy operation on the tail of the pass
 __global__ void k_publish(const Summary* sum, Summary* host_sum) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *host_sum = *sum;
+}
+
+// ---- k_tail_small: the whole tail of a SMALL pass (a GNU Radio work() call: a few lists, a few hundred centres at most)
+// in one workgroup and one launch -- long pulses, scan, gather, gate, count, compact, publish, with workgroup barriers
+// where the multi-kernel chain has kernel boundaries.  Such a pass is bound by the number of GPU operations, not by their size:
+// seven launches fewer.  (Writes of one phase are read by other wavefronts of the SAME workgroup in the next: the
+// workgroup-scope ordering of __syncthreads() is what that needs.)
+struct TailArgs {
+  const unsigned long long* cands; const Rec* recs; const int* blk_count; const long long* blk_lastp; const unsigned* blk_flags;
+  int* blk_off; int nblk, rec_cap; int* long_count; unsigned long long* long_lastp;
+  unsigned long long* sorted; Rec* sorted_recs; int* seg_count; Summary* sum; Summary* host_sum; Rec* out; int out_cap;
+  int gate_on, head_n; long long gate, gate_long, prev_eob;
+};
+template <int MODE>
+__global__ void __launch_bounds__(kThreads) k_tail_small(DetectArgs a, TailArgs t) {
+  longrun_body<MODE>(0, 1, a);                                // pulses longer than k_detect's LDS window (usually none)
+  __syncthreads();
+  scan_body(t.blk_count, t.blk_lastp, t.blk_flags, t.nblk, t.rec_cap, t.long_count, t.long_lastp, t.blk_off, t.sum);
+  __syncthreads();
+  gather_body(0, 1, t.cands, t.recs, t.blk_count, t.blk_off, t.nblk, t.rec_cap, t.sorted, t.sorted_recs);
+  __syncthreads();
+  unsigned fmask = 0u, fwant = 0u;
+  if (t.gate_on) {
+    resolve_body(0, 1, t.sorted, t.sum, t.gate, t.gate_long, t.prev_eob);
+    fmask = kKept; fwant = kKept;
+    __syncthreads();
+  }
+  count_body(0, 1, t.sorted, t.sum, fmask, fwant, t.head_n, t.seg_count);
+  __syncthreads();
+  compact_body(0, 1, t.sorted, t.sorted_recs, t.sum, t.seg_count, fmask, fwant, t.head_n, t.out, t.out_cap, t.long_count,
+               t.long_lastp);
+  __syncthreads();
+  if (threadIdx.x == 0) *t.host_sum = *t.sum;
 }
 
 // ---- k_slice: PPM slice (+ optional confidence ratio) for a caller-supplied tag list ---------------

@@ -203,6 +203,10 @@ void launch_longrun(hipStream_t st, const DetectArgs& a) {
   hipLaunchKernelGGL((k_longrun<MODE>), dim3(64), dim3(kThreads), 0, st, a);
 }
 template <int MODE>
+void launch_tail_small(hipStream_t st, const DetectArgs& a, const TailArgs& t) {
+  hipLaunchKernelGGL((k_tail_small<MODE>), dim3(1), dim3(kThreads), 0, st, a, t);
+}
+template <int MODE>
 void launch_confidence(hipStream_t st, int grid, const DetectArgs& a, const Rec* out, const Summary* sum, int cap, float* ratio) {
   hipLaunchKernelGGL((k_confidence<MODE>), dim3(grid), dim3(kThreads), 0, st, a, out, sum, cap, ratio);
 }
@@ -213,6 +217,20 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   const Plan& pl = s.plan;
   Misc* misc = (Misc*)s.d_misc.p;
   hipStream_t ts = c->stream;
+  if (s.direct) {
+    // a small pass (few lists, at most kDirectRecs centres): the whole tail in one workgroup and one launch, on the
+    // compute stream right behind its k_detect (nothing to overlap: the pass is a few microseconds of GPU time)
+    TailArgs t;
+    t.cands = a.cands; t.recs = a.recs; t.blk_count = a.blk_count; t.blk_lastp = a.blk_lastp; t.blk_flags = a.blk_flags;
+    t.blk_off = (int*)s.d_blk_off.p; t.nblk = s.nlists; t.rec_cap = s.rec_cap; t.long_count = a.long_count;
+    t.long_lastp = a.long_lastp; t.sorted = (unsigned long long*)s.d_sorted.p; t.sorted_recs = (Rec*)s.d_sorted_recs.p;
+    t.seg_count = (int*)s.d_seg.p; t.sum = &misc->sum; t.host_sum = s.h_sum; t.out = (Rec*)s.h_out; t.out_cap = (int)s.tot;
+    t.gate_on = pl.gate ? 1 : 0; t.head_n = pl.head_n; t.gate = 63ll * c->sps;
+    t.gate_long = (long long)(pl.long_aware ? 119 : 63) * c->sps; t.prev_eob = pl.prev_eob_stream - pl.origin;
+    ADSB_BY_MODE(pl.mode, launch_tail_small, ts, a, t);
+    HIPCHK(c, hipEventRecord(s.done, ts));
+    return 0;
+  }
   if (c->split_tail) {
     // tail on its own stream, ordered after this pass's k_detect/k_longrun only: the next pass's k_detect can
     // start on the compute stream while this runs

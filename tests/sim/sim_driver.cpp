@@ -20,6 +20,7 @@ struct SimOut {
 };
 
 static float* g_conf_out = nullptr; // sim_set_confidence_out: [n_kept][112] ratios of the next run (k_confidence), or null
+static int g_tail_mode = 0;         // sim_set_tail_mode
 static int g_long_aware = 0;      // opt-in length-aware gate (ADSB_FLAG_LONG_AWARE_GATE): set by sim_set_long_aware
 
 #define SIM_BY_MODE(mode, K, ...)                          \
@@ -66,7 +67,7 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   std::vector<LongRise> longlist(ntiles + 1);
   int long_count = 0;
   unsigned long long long_lastp = 0;
-  Summary sum;
+  Summary sum, sum_host;
 
   DetectArgs a;
   a.data = dbuf; a.n = n; a.in0_base = in0_base; a.scan_lo = scan_lo; a.scan_hi = scan_hi; a.fall_hi = fall_hi;
@@ -78,8 +79,22 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   a.long_lastp = &long_lastp;
 
   SIM_BY_MODE(mode, k_detect, grid, kThreads, a);
-  SIM_BY_MODE(mode, k_longrun, 3, kThreads, a);
-  {
+  // same choice as adsb_hip.hip: enqueue_tail(): small passes take the one-workgroup tail (g_tail_mode: 0 = as the
+  // library decides, 1 = always the kernel chain, 2 = always the fused tail)
+  const bool fused = g_tail_mode == 2 || (g_tail_mode == 0 && tot <= 16384);
+  if (fused) {
+    TailArgs t;
+    t.cands = cands.data(); t.recs = recs.data(); t.blk_count = blk_count.data(); t.blk_lastp = blk_lastp.data();
+    t.blk_flags = blk_flags.data(); t.blk_off = blk_off.data(); t.nblk = nlists; t.rec_cap = rec_cap;
+    t.long_count = &long_count; t.long_lastp = &long_lastp; t.sorted = sorted.data(); t.sorted_recs = sorted_recs.data();
+    t.seg_count = seg.data(); t.sum = &sum; t.host_sum = &sum_host; t.out = outv.data(); t.out_cap = (int)tot;
+    t.gate_on = gate ? 1 : 0; t.head_n = head_n; t.gate = 63ll * sps; t.gate_long = (long long)(g_long_aware ? 119 : 63) * sps;
+    t.prev_eob = prev_eob_stream - origin;
+    SIM_BY_MODE(mode, k_tail_small, 1, kThreads, a, t);
+    sum = sum_host;
+    if (g_conf_out) SIM_BY_MODE(mode, k_confidence, 2, kThreads, a, (const Rec*)outv.data(), (const Summary*)&sum, (int)tot, g_conf_out);
+  } else {
+    SIM_BY_MODE(mode, k_longrun, 3, kThreads, a);
     hipsim::launch(k_scan, 1, kThreads, (const int*)blk_count.data(), (const long long*)blk_lastp.data(),
                    (const unsigned*)blk_flags.data(), nlists, rec_cap, (const int*)&long_count,
                    (const unsigned long long*)&long_lastp, blk_off.data(), &sum);
@@ -111,6 +126,7 @@ void sim_set_long_aware(int v) { g_long_aware = v; }
 // the kernel's tile geometry, so that seam-targeted tests follow it
 void sim_geometry(int* tile, int* fwd, int* back) { *tile = kWTile; *fwd = kFwd; *back = kBack; }
 void sim_set_confidence_out(float* p) { g_conf_out = p; }
+void sim_set_tail_mode(int m) { g_tail_mode = m; }
 
 // --- the library's three call shapes, through the same adsb_plan.h the library uses ------------------
 int sim_canonical(int mode, const float* data, long long n, long long abs_offset, float thr, int sps, int grid_max,

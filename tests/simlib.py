@@ -136,6 +136,19 @@ def unpack_bits(bits14):
     return np.unpackbits(np.asarray(bits14, dtype=np.uint8).reshape(-1, 14), axis=1, bitorder="big")
 
 
+class tail_mode:
+    """with simlib.tail_mode(1): ... -- 1 = always the tail kernel chain, 2 = always the one-workgroup fused tail
+    (0 = the library's own choice by pass size)."""
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        lib().sim_set_tail_mode(self.mode)
+
+    def __exit__(self, *a):
+        lib().sim_set_tail_mode(0)
+
+
 class long_aware_gate:
     """with simlib.long_aware_gate(): ... -- the emulated device code runs with ADSB_FLAG_LONG_AWARE_GATE semantics."""
     def __enter__(self):

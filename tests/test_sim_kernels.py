@@ -233,6 +233,44 @@ def test_replay_blocks_equal_one_canonical_call(bps, block, head, growth, monkey
     assert np.all((got["flags"] & 2) != 0) and not np.any(got["flags"] & 16)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("name", golden_names())
+def test_both_tails_match_goldens(name, mode):
+    """The tail as a chain of kernels (bulk passes) and as ONE workgroup (k_tail_small: small passes, e.g. every GNU
+    Radio work() call) are the same bodies run two ways: both must reproduce the goldens, canonical and chunked."""
+    g = Golden(name)
+    with simlib.tail_mode(mode):
+        recs, _ = simlib.sim_canonical(0, g.iq, g.fs, g.thr)
+        assert_recs_match_golden(recs, g)
+        fr = simlib.SimFramer(g.fs, g.thr)
+        H = 8 * g.sps
+        buf = np.concatenate([np.zeros(H - 1, np.float32), g.x])
+        pos, offs = 0, []
+        for N in g.sched("random"):
+            r, _ = fr.work(buf[pos:pos + N + H - 1], N, pos)
+            offs.append(r["offset"])
+            pos += N
+        assert np.array_equal(np.concatenate(offs), g.get("random", "tag_offsets"))
+        assert fr.prev_eob.value == int(g.get("random", "final_prev_eob"))
+
+
+def test_fused_tail_with_many_lists_and_shard_heads():
+    """k_tail_small on its limits: a few hundred lists (several k_scan rounds), head records of a gated shard."""
+    fs, n = 2e6, 170_000
+    iq = M.synth_iq(n, fs, 8000, seed=33)
+    want = C.canonical(O.mag2(iq), 2, np.float32(0.01))
+    for mode in (1, 2):
+        with simlib.tail_mode(mode):
+            got, so = simlib.sim_canonical(0, iq, fs, 0.01, grid_max=160, rec_cap=40)
+            assert so.overflow == 0
+            assert_recs_equal(got, want, "tail mode %d" % mode)
+            a = simlib.sim_shard(0, iq[:90000], 0, 0, 80000, n, fs, 0.01, head_cands=16, grid_max=40)[0]
+            if mode == 1:
+                ref = a
+            else:
+                assert a.tobytes() == ref.tobytes()
+
+
 def test_many_units():
     """A grid of 40 workgroups = 160 per-wavefront lists: ordering across many units (k_scan / k_gather)."""
     fs, n = 2e6, 170_000

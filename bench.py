@@ -410,9 +410,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # ADSB_BENCH_ONE_GPU=1: debugging aid -- run the N-rank code path with every rank on cuda:0 (gloo only)
     one_gpu = os.environ.get("ADSB_BENCH_ONE_GPU") == "1"
+    host_group = None     # host-side collectives (mailbox set-up, object gathers, fallbacks): always gloo, never RCCL
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo" if one_gpu else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        host_group = dist.new_group(backend="gloo")
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
     n_gpus = world
     if one_gpu:
@@ -492,12 +494,12 @@ def main():
         return len(kept)
 
     # 16 bytes per rank per pass, host side: shared-memory mailbox on one node, gloo all_gather across nodes
-    ag_int, ag_close = sharding.make_pair_exchange(dist, rank, n_gpus) if n_gpus > 1 else (None, lambda: None)
+    ag_int, ag_close = sharding.make_pair_exchange(dist, rank, n_gpus, group=host_group) if n_gpus > 1 else (None, lambda: None)
     transport = None if n_gpus == 1 else ("shm mailbox" if getattr(ag_int, "__self__", None) is not None else "gloo all_gather")
 
     def ag_obj(o):
         out = [None] * n_gpus
-        dist.all_gather_object(out, o)
+        dist.all_gather_object(out, o, group=host_group)
         return out
 
     def drain():
@@ -521,17 +523,20 @@ def main():
     elif one_gpu:
         sync_dev[0] = "cpu"
 
+    def sync_group():
+        return host_group if sync_dev[0] == "cpu" else None          # RCCL (default group) or the gloo fallback
+
     def sync_all():
         torch.cuda.synchronize()
         if n_gpus > 1:
-            dist.all_reduce(torch.zeros(1, device=sync_dev[0]))      # barrier
+            dist.all_reduce(torch.zeros(1, device=sync_dev[0]), group=sync_group())      # barrier
             torch.cuda.synchronize()
 
     def reduce_max(t):
         if n_gpus == 1:
             return t
         tmax = torch.tensor([t], dtype=torch.float64, device=sync_dev[0])
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=sync_group())
         return float(tmax.item())
 
     # the same kernel timed without a neighbour, BEFORE the timed region (it also brings a fresh box's clocks up)
@@ -605,6 +610,7 @@ def main():
                                "AWGN 2e-3" if args.mixed_df else "AWGN 1e-3", args.threshold, args.log2n),
                 "fs": fs, "samples_per_gpu_per_step": n_own, "bursts_per_step_rank0": int(n_bursts),
                 "sharding": "none" if n_gpus == 1 else "%d overlapped time shards, host stitch" % n_gpus,
+                "rank_sync": None if n_gpus == 1 else ("gloo" if sync_dev[0] == "cpu" else "rccl"),
                 "pipeline": "%d passes in flight (submit/wait)%s" % (DEPTH, (", single stream" if args.single_stream else "") + (", low-latency tail" if args.low_latency else "")),
                 "detect_gap_ms_avg": round(st["detect_gap_ms"] / max(1, st["detect_gaps"]), 4),
                 "detect_grid": int(st["detect_grid"]), "retries": int(st["retries"]), "longrun_calls": int(st["longrun_calls"]),

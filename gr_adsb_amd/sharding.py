@@ -78,10 +78,11 @@ class ShmPairExchange:
             pass
 
 
-def make_pair_exchange(dist, rank, world):
+def make_pair_exchange(dist, rank, world, group=None):
     """The cheapest correct transport for finish_shard's one exchange: a shared-memory mailbox when every
     rank runs on this node (torchrun sets LOCAL_WORLD_SIZE == WORLD_SIZE; ADSB_SHARD_EXCHANGE=gloo overrides),
-    else the process group's own all_gather.  Returns (all_gather_pair, close)."""
+    else the process group's own all_gather.  group: the (host-side, gloo) process group to set the mailbox up with /
+    to gather over -- None = the default group.  Returns (all_gather_pair, close)."""
     import torch
     same_node = os.environ.get("LOCAL_WORLD_SIZE") == str(world) and os.path.isdir("/dev/shm") \
         and os.environ.get("ADSB_SHARD_EXCHANGE", "shm") == "shm"
@@ -90,16 +91,16 @@ def make_pair_exchange(dist, rank, world):
         if rank == 0:
             name[0] = "/dev/shm/adsb_xchg_%d_%d" % (os.getpid(), int(time.time() * 1e6) & 0xFFFFFFFF)
             ShmPairExchange(name[0], 0, world, create=True).close()
-        dist.broadcast_object_list(name, src=0)
+        dist.broadcast_object_list(name, src=0, group=group)
         x = ShmPairExchange(name[0], rank, world, create=False)
-        dist.barrier()                               # everyone has it mapped ...
+        dist.barrier(group=group)                    # everyone has it mapped ...
         if rank == 0:
             os.unlink(name[0])                       # ... so the name can go: nothing is left behind on a crash
         return x.all_gather_pair, x.close
 
     def ag(pair):
         out = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(out, torch.tensor([int(pair[0]), int(pair[1])], dtype=torch.int64))
+        dist.all_gather(out, torch.tensor([int(pair[0]), int(pair[1])], dtype=torch.int64), group=group)
         return [(int(t[0]), int(t[1])) for t in out]
     return ag, (lambda: None)
 

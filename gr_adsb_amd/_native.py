@@ -42,7 +42,7 @@ EXPORTS = [
     "adsb_set_format_scale", "adsb_process_format", "adsb_process_format_device", "adsb_submit_format_device",
     "adsb_submit_format_host", "adsb_last_confidence",
     "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_shard_host", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_mode_s_syndrome", "adsb_get_stats",
-    "adsb_reset_stats", "adsb_last_error", "adsb_host_alloc", "adsb_host_free",
+    "adsb_reset_stats", "adsb_last_error", "adsb_host_alloc", "adsb_host_free", "adsb_host_register", "adsb_host_unregister",
 ]
 
 
@@ -120,6 +120,8 @@ def load():
     lib.adsb_reset_stats.argtypes = [vp]
     lib.adsb_host_alloc.argtypes = [c.POINTER(vp), c.c_size_t]
     lib.adsb_host_free.argtypes = [vp]
+    lib.adsb_host_register.argtypes = [vp, c.c_size_t]
+    lib.adsb_host_unregister.argtypes = [vp]
     lib.adsb_last_error.argtypes = [vp]
     lib.adsb_last_error.restype = c.c_char_p
     _lib = lib
@@ -353,6 +355,37 @@ class PinnedArray:
             if self._p.value:
                 self.lib.adsb_host_free(self._p)
                 self._p = ctypes.c_void_p()
+        except Exception:
+            pass
+
+
+class RegisteredArray:
+    """Page-locks an existing NumPy array in place (adsb_host_register) for as long as this object lives, so that
+    host-fed submissions DMA it where it lies.  `with RegisteredArray(a): ...` or keep the object around."""
+
+    def __init__(self, array):
+        self.lib = load()
+        self.array = np.ascontiguousarray(array)
+        assert self.array is array or self.array.base is array or np.shares_memory(self.array, array), "array must be contiguous"
+        rc = self.lib.adsb_host_register(ctypes.c_void_p(self.array.ctypes.data), self.array.nbytes)
+        if rc != 0:
+            raise AdsbError(rc, "adsb_host_register")
+        self._live = True
+
+    def close(self):
+        if getattr(self, "_live", False):
+            self.lib.adsb_host_unregister(ctypes.c_void_p(self.array.ctypes.data))
+            self._live = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

@@ -991,6 +991,19 @@ int adsb_host_free(void* p) {
   return hipHostFree(p) == hipSuccess ? 0 : -EINVAL;
 }
 
+int adsb_host_register(void* p, size_t bytes) {
+  if (!p || bytes == 0) return -EINVAL;
+  const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorHostMemoryAlreadyRegistered ? -EEXIST : -ENOMEM; }
+  return 0;
+}
+
+int adsb_host_unregister(void* p) {
+  if (!p) return -EINVAL;
+  if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return -EINVAL; }
+  return 0;
+}
+
 int adsb_get_stats(adsb_ctx* c, adsb_stats* out) {
   if (!c || !out) return -EINVAL;
   *out = c->stats;

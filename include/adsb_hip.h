@@ -142,6 +142,12 @@ int adsb_process_mag2(adsb_ctx* ctx, const float* mag2_host, int64_t n, int64_t 
  * buffers are first copied into the context's own pinned staging buffer (about 3x slower end to end). */
 int adsb_host_alloc(void** p, size_t bytes);
 int adsb_host_free(void* p);
+/* Page-lock a buffer the caller already owns (e.g. the ring an SDR driver or a file mapping fills), so that
+ * adsb_process_* / adsb_submit_format_host DMA it where it lies instead of copying it through the context's staging
+ * chunks (about half the rate).  Registration costs milliseconds: do it once per buffer, not per call; unregister before
+ * freeing the memory.  Thin wrappers over hipHostRegister / hipHostUnregister for callers that do not link HIP. */
+int adsb_host_register(void* p, size_t bytes);
+int adsb_host_unregister(void* p);
 
 /* Same, input already in HBM (16-byte aligned device pointer).  out may be NULL: the result stays in
  * the context's pinned buffer, see adsb_last_result. */

@@ -775,6 +775,10 @@ def test_host_fed_pipeline_equals_blocking_calls(native):
             r = recs.copy()
             r["offset"] -= off
             assert_recs_equal(r, want[j], "host-fed chunk %d" % j)
+    # a caller-owned pageable buffer page-locked in place (adsb_host_register): same results, DMA'd where it lies
+    with native.RegisteredArray(chunks[1]) as reg:
+        t = ctx.submit_format_host(native.FMT_FC32, reg.array)
+        assert_recs_equal(ctx.wait(t), want[1], "registered chunk")
     # int16 chunks through the same entry (4 B/sample)
     q = M.quantize_iq16(chunks[0])
     ctx.set_iq16_scale(2.0 / 32767.0)

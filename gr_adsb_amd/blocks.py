@@ -121,7 +121,7 @@ class framer(gr.sync_block):
         if self.improved:
             return self._work_improved(in0, out0)
         bursts = self._ctx.framer_work(in0[:N + self.N_hist - 1], N, self.nitems_written(0))
-        snr = _native.snr_db(bursts["peak"], bursts["median"])
+        snr = _native.snr_db(bursts["peak"], bursts["median"]) if len(bursts) else ()     # (most work() calls carry no burst)
         for b, s in zip(bursts, snr):
             self.add_item_tag(
                 0,

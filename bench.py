@@ -401,9 +401,10 @@ def main():
     ap.add_argument("--low-latency", action="store_true", help="ADSB_FLAG_LOW_LATENCY: tail kernels beside the next pass's k_detect")
     ap.add_argument("--single-stream", action="store_true",
                     help="profiling aid (ADSB_FLAG_SINGLE_STREAM): the sparse tail of a pass behind its k_detect on one stream")
-    ap.add_argument("--format", choices=["fc32", "sc16", "sc8", "cu8"], default="fc32",
-                    help="input sample format: complex64 (BASELINE workload), int16 IQ (4 B/sample) or 8-bit IQ "
-                         "(2 B/sample: int8 / RTL-SDR offset binary); integer formats N=1 only")
+    ap.add_argument("--format", choices=["fc32", "mag2", "sc16", "sc8", "cu8"], default="fc32",
+                    help="input sample format: complex64 (BASELINE workload), float32 |IQ|^2 (the framer's literal input, "
+                         "4 B/sample), int16 IQ (4 B/sample) or 8-bit IQ (2 B/sample: int8 / RTL-SDR offset binary); "
+                         "formats other than fc32 N=1 only")
     args = ap.parse_args()
 
     stray = sorted(k for k in os.environ if k.startswith("ADSB_") and k not in KNOWN_ENV)
@@ -443,14 +444,18 @@ def main():
                   flags=(_native.FLAG_SINGLE_STREAM if args.single_stream else 0) | (_native.FLAG_LOW_LATENCY if args.low_latency else 0))
 
     intfmt = args.format != "fc32"
-    fmt = {"fc32": _native.FMT_FC32, "sc16": _native.FMT_SC16, "sc8": _native.FMT_SC8, "cu8": _native.FMT_CU8}[args.format]
+    fmt = {"fc32": _native.FMT_FC32, "mag2": _native.FMT_MAG2, "sc16": _native.FMT_SC16, "sc8": _native.FMT_SC8,
+           "cu8": _native.FMT_CU8}[args.format]
     assert not (intfmt and n_gpus > 1)
     synth = dict(noise_power=2e-3, df_choices=DF_MIX[0], df_weights=DF_MIX[1], snr_db_range=(3.0, 25.0)) if args.mixed_df else {}
     if n_gpus == 1:
         iq = gen_stream_blocks(n_own, 0, fs, args.bursts, args.seed, dev, **synth)
         plan = None
         # quantise the same stream to the integer wire format (full scale 4.0); the kernel converts with the same scale
-        if fmt == _native.FMT_SC16:
+        if fmt == _native.FMT_MAG2:
+            # |IQ|^2 of the same stream with separately rounded products, computed once outside the timed region
+            iq = (iq[:, 0] * iq[:, 0] + iq[:, 1] * iq[:, 1]).contiguous()
+        elif fmt == _native.FMT_SC16:
             fe.ctx.set_format_scale(fmt, 4.0 / 32767.0)
             iq = torch.clamp(torch.round(iq * (32767.0 / 4.0)), -32768, 32767).to(torch.int16).contiguous()
         elif fmt == _native.FMT_SC8:
@@ -605,7 +610,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.format == "fc32" else {"sc16": "i16->f32", "sc8": "i8->f32", "cu8": "u8->f32"}[args.format],
+            "dtype": "f32" if args.format in ("fc32", "mag2") else {"sc16": "i16->f32", "sc8": "i8->f32", "cu8": "u8->f32"}[args.format],
             "data": "synthetic",
             "timing": {"repeats": len(times), "steps_per_repeat": args.steps, "timed_seconds": round(sum(times), 4),
                        "ms_per_step_min": round(min(times) / args.steps * 1e3, 4),
@@ -615,7 +620,7 @@ def main():
             "config": {
                 "workload": "synthetic %g Msps %s IQ, %g %s bursts/s, %s, threshold %g; "
                             "2^%d samples per GPU per step resident in HBM; one canonical framer+demod pass"
-                            % (fs / 1e6, {"fc32": "complex64", "sc16": "int16", "sc8": "int8", "cu8": "uint8 offset-binary"}[args.format], args.bursts,
+                            % (fs / 1e6, {"fc32": "complex64", "mag2": "float32 |IQ|^2 of complex64", "sc16": "int16", "sc8": "int8", "cu8": "uint8 offset-binary"}[args.format], args.bursts,
                                "mixed-DF (docs/DF_histogram.txt proportions, SNR 3-25 dB)" if args.mixed_df else "DF17-length",
                                "AWGN 2e-3" if args.mixed_df else "AWGN 1e-3", args.threshold, args.log2n),
                 "fs": fs, "samples_per_gpu_per_step": n_own, "bursts_per_step_rank0": int(n_bursts),

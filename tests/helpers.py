@@ -10,8 +10,28 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SCHEDULES = ("single", "fixed4096", "fixed8192", "random")
 
 
+def _names(pattern):
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, pattern)))
+
+
 def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "g*msps*.npz")))
+    """Round-1 vectors: 2^17 samples of int16 IQ per rate, four chunk schedules (tools/make_golden.py)."""
+    return _names("g*msps*.npz")
+
+
+def large_golden_names():
+    """Round-3 vectors: 2^20 .. 3*2^20 samples of int8 IQ per rate, >= 500 tags each (tools/make_golden_large.py)."""
+    return _names("L*.npz")
+
+
+def pathological_names():
+    """Round-3 vectors: float32 |IQ|^2 with NaN / inf, thresholds <= 0, multi-tile plateaus, ties, tiny inputs."""
+    return _names("P*.npz")
+
+
+def schedules_of(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    return [k[:-len("_schedule")] for k in z.files if k.endswith("_schedule")]
 
 
 class Golden:
@@ -21,8 +41,19 @@ class Golden:
         self.fs = float(z["fs"])
         self.sps = int(self.fs // 1e6)
         self.thr = float(z["threshold"])
-        self.iq = M.dequantize_iq16(z["iq16"])
-        self.x = M.mag2(self.iq)
+        self.iq = self.iq8 = None
+        if "iq16" in z.files:
+            self.iq = M.dequantize_iq16(z["iq16"])
+            self.x = M.mag2(self.iq)
+        elif "iq8" in z.files:
+            # the cs8 wire format: component = f32(int8) * scale (one rounded multiply), then re*re + im*im
+            self.iq8 = z["iq8"]
+            self.scale = np.float32(z["scale"])
+            v = self.iq8.astype(np.float32) * self.scale
+            self.iq = (v[0::2] + 1j * v[1::2]).astype(np.complex64)
+            self.x = M.mag2(self.iq)
+        else:
+            self.x = z["x"]
         self.z = z
 
     def sched(self, s):

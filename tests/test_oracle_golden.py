@@ -5,7 +5,8 @@ import os
 import numpy as np
 import pytest
 
-from helpers import GOLDEN_DIR, SCHEDULES, Golden, golden_names, snr_bits, unpack
+from helpers import (GOLDEN_DIR, SCHEDULES, Golden, golden_names, large_golden_names, pathological_names, schedules_of,
+                     snr_bits, unpack)
 from oracle import adsb_oracle as O
 from oracle import c_oracle as C
 
@@ -34,6 +35,51 @@ def test_c_oracle_matches_reference_goldens(name):
     dem = (r["flags"] & 1) != 0
     assert np.array_equal(r["offset"][dem], g.get("single", "pdu_offsets"))
     assert np.array_equal(unpack(r["bits"][dem]), g.pdu_bits("single"))
+
+
+def _numpy_oracle_vs(g, sched):
+    with np.errstate(all="ignore"):
+        o = O.run_stream(g.x, g.fs, g.thr, None if sched == "single" else g.sched(sched))
+    assert np.array_equal(o["tag_offsets"], g.get(sched, "tag_offsets"))
+    assert np.array_equal(o["tag_snr"].view(np.uint32), g.get(sched, "tag_snr_bits"))
+    assert np.array_equal(o["pdu_offsets"], g.get(sched, "pdu_offsets"))
+    assert np.array_equal(o["pdu_bits"], g.pdu_bits(sched))
+    assert np.array_equal(o["pdu_snr"].view(np.uint32), g.get(sched, "pdu_snr_bits"))
+    assert o["final_prev_eob"] == int(g.get(sched, "final_prev_eob"))
+    assert np.float32(o["final_prev_in0"]).view(np.uint32) == g.get(sched, "final_prev_in0_bits")
+    if sched == "single":
+        assert np.array_equal(o["pdu_conf"].view(np.uint32), g.get(sched, "pdu_conf_bits"))
+
+
+def _c_oracle_vs(g):
+    r = C.canonical(g.x, g.sps, np.float32(g.thr))
+    assert np.array_equal(r["offset"], g.get("single", "tag_offsets"))
+    assert np.array_equal(snr_bits(r["peak"], r["median"]), g.get("single", "tag_snr_bits"))
+    dem = (r["flags"] & 1) != 0
+    assert np.array_equal(r["offset"][dem], g.get("single", "pdu_offsets"))
+    assert np.array_equal(unpack(r["bits"][dem]), g.pdu_bits("single"))
+
+
+@pytest.mark.parametrize("name", large_golden_names())
+def test_oracles_match_large_reference_goldens(name):
+    """tests/golden/L*.npz: >= 500 reference tags per rate (20 Msps included), incl. the fixed-2048 deaf-state schedule."""
+    g = Golden(name)
+    assert len(g.get("single", "tag_offsets")) >= 490
+    for sched in schedules_of(name):
+        _numpy_oracle_vs(g, sched)
+    _c_oracle_vs(g)
+    if g.iq8 is not None:                              # the C port's own int8 conversion on the same bytes
+        assert np.array_equal(O.mag2_iq8(g.iq8, float(g.scale), False), g.x)
+
+
+@pytest.mark.parametrize("name", pathological_names())
+def test_oracles_match_pathological_reference_goldens(name):
+    """tests/golden/P*.npz: NaN / inf, thresholds <= 0, plateaus over several tiles, start / end high, ties, tiny inputs
+    -- the reference's own outputs, so the GPU box does not rest on the C oracle alone for these."""
+    g = Golden(name)
+    for sched in schedules_of(name):
+        _numpy_oracle_vs(g, sched)
+    _c_oracle_vs(g)
 
 
 def test_c_oracle_equals_numpy_oracle_on_fresh_synthetic():

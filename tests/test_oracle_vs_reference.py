@@ -110,3 +110,35 @@ def test_parity_oracle_matches_live_reference_decoder():
                 dec.plane_dict[dec.aa_str] = {"callsign": ""}
                 known_aa.add(dec.aa)
     assert len(known_aa) > 20
+
+
+def test_c_oracle_equals_live_reference_on_adversarial_streams():
+    """The scalar C port (oracle/adsb_oracle.c) is what the GPU box checks the HIP path against on pathological streams;
+    here it meets the UNMODIFIED reference directly on 300 streams from the seam-targeted adversarial generator
+    (plateaus over tile seams, exact ties, NaN, thresholds <= 0 and sitting on sample values, sps 2/4/8/20)."""
+    import warnings
+    from oracle import c_oracle as C
+    from helpers import snr_bits, unpack
+    from test_sim_property import adversarial_stream
+    R = _ref()
+    n_tags = 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for seed in range(300):
+            rng = np.random.default_rng(7000 + seed)
+            n = int(rng.choice([1, 17, 240, 1023, 1024, 1025, 1279, 1280, 1281, 2049, 3333, 4096, 4352, 8193, 12288, 30000]))
+            sps = int(rng.choice([2, 4, 8, 20]))
+            thr = float(rng.choice([0.01, 0.0099, 0.0101, 0.004, 0.05, 0.0, -1.0]))
+            x = adversarial_stream(rng, n, sps)
+            if seed % 5 == 0:
+                x[rng.integers(0, n, 2)] = np.inf
+            r = R.run_reference(x, sps * 1e6, thr)
+            c = C.canonical(x, sps, np.float32(thr))
+            what = "seed %d n %d sps %d thr %g" % (seed, n, sps, thr)
+            assert np.array_equal(c["offset"], r["tag_offsets"]), what
+            assert np.array_equal(snr_bits(c["peak"], c["median"]), r["tag_snr"].view(np.uint32)), what
+            dem = (c["flags"] & 1) != 0
+            assert np.array_equal(c["offset"][dem], r["pdu_offsets"]), what
+            assert np.array_equal(unpack(c["bits"][dem]), r["pdu_bits"]), what
+            n_tags += len(c)
+    assert n_tags > 150

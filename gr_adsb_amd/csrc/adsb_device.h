@@ -49,23 +49,9 @@ constexpr long long kNoIndex = -(1ll << 62);
 static_assert(kWOwn == 16 && kFwd % 64 == 0, "word owners are lanes 0..15 of each wavefront");
 static_assert(kBack % 64 == 0 && kBack >= 100, "the noise window of a centre in the tile must lie in the LDS window");
 
-// k_detect is latency bound per workgroup: 5 resident workgroups per CU (<= 96 VGPRs, no spills) measured
-// 15-20 % faster than 4; 6 would need spills to scratch.
-// Number of prefetch registers (of Span::ITER) reloaded inside the commit loop, right after their samples were
-// converted; the others are reloaded after the commit.  More = less time without a fetch in flight, but the
-// reloaded registers stay live through the rest of the commit (VGPR pressure: 8 costs the fifth wavefront per SIMD).
-#ifndef ADSB_EARLY_ISSUE
-#define ADSB_EARLY_ISSUE 4
-#endif
-constexpr int kEarlyIssue = ADSB_EARLY_ISSUE;
-#ifndef ADSB_MIN_WAVES
-#define ADSB_MIN_WAVES 5
-#endif
-// how k_detect turns a tile's rise mask into its ordered rise list: 1 = every lane walks its own 16 samples (shipped),
-// 0 = word by word with one lane per bit (round 1)
-#ifndef ADSB_RISE_BY_LANE
-#define ADSB_RISE_BY_LANE 1
-#endif
+// k_detect: five resident workgroups per CU (<= 96 VGPRs, 31 KB of LDS each); the tail kernels of the previous pass
+// are sized to fit beside them (tests/test_abi.py holds the limits).
+constexpr int kMinWaves = 5;
 
 enum RecFlags : unsigned {
   kDemod = 1u,     // eob inside the demod input: bits valid (demod.py:82)
@@ -361,45 +347,62 @@ __device__ __forceinline__ BurstFetch<MODE> burst_issue(const DetectArgs& a, uns
 // stores the 32-byte record.
 __device__ __forceinline__ void burst_reduce(long long offset, int nwin, bool val0, bool val1, float peak, float v0,
                                              float v1, bool dem, float x1, float x0, float y1, float y0, unsigned xflags,
-                                             Rec* out, int lane, const ParityConsts& pc) {
+                                             Rec* out, int lane) {
   const unsigned long long nanm = __ballot((val0 && v0 != v0) || (val1 && v1 != v1));
   const unsigned k0 = val0 ? f32_key(v0) : 0xFFFFFFFFu;      // lanes outside the window sort last
   const unsigned k1 = val1 ? f32_key(v1) : 0xFFFFFFFFu;
-  // exact MSB-first select of the lower middle (the middle for odd n): the answer's known high bits are `prefix`;
-  // bit b is set iff at most kt keys lie below prefix | 1<<b.  One compare per key per step; prefix, c, kt are
-  // wave-uniform and live in scalar registers.
+  // Exact select of the lower middle (the middle for odd n), rank kt: binary search for the largest T with at most kt
+  // keys below it, one bit per step (one compare per key per step; lo, the count and kt are wave-uniform scalars).
+  // The interval [lo, lo + 2^bit) always holds the key of rank kt.
   const int kt = adsb_uniform((nwin - 1) >> 1);
-  unsigned prefix = 0;
-  for (int bit = 31; bit >= 0; --bit) {
-    const unsigned T = prefix | (1u << bit);
-    const int c = adsb_uniform(__popcll(__ballot(k0 < T)) + __popcll(__ballot(k1 < T)));
-    if (c <= kt) prefix = T;
+  unsigned lo = 0u, span = 0u;
+  bool single = false;
+  // Eight rounds of four steps.  After 16, 20 and 24 decided bits: does the interval [lo, lo + 2^bit) hold exactly one
+  // key?  Then that key IS the answer -- the usual case for float noise after 16 bits (half the steps); streams
+  // quantised to a few levels (8-bit IQ) hold duplicates around the median and simply run all 32 steps.
+  for (int bit = 31; bit >= 0; bit -= 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned T = lo | (1u << (bit - j));
+      const int c = adsb_uniform(__popcll(__ballot(k0 < T)) + __popcll(__ballot(k1 < T)));
+      if (c <= kt) lo = T;
+    }
+    if (bit <= 19 && bit >= 11) {
+      const unsigned sp = 1u << (bit - 3);
+      const int inside = adsb_uniform(__popcll(__ballot(k0 - lo < sp)) + __popcll(__ballot(k1 - lo < sp)));
+      if (inside == 1) { single = true; span = sp; break; }
+    }
   }
-  const unsigned A = prefix;                                 // key of the lower middle
+  unsigned A = lo;                                           // key of the lower middle
+  if (single) {                                              // wave-uniform: fetch the one key inside [lo, lo + span)
+    const unsigned long long m0 = __ballot(k0 - lo < span), m1 = __ballot(k1 - lo < span);
+    const unsigned a0 = (unsigned)adsb_readlane((int)k0, m0 ? __builtin_ctzll(m0) : 0);
+    const unsigned a1 = (unsigned)adsb_readlane((int)k1, m1 ? __builtin_ctzll(m1) : 0);
+    A = m0 ? a0 : a1;
+  }
   float med;
   if (nwin == 0) med = __builtin_bit_cast(float, 0xFFC00000u);       // np.median([]) == 0/0: default NaN, sign set
   else if (nanm) med = __builtin_bit_cast(float, 0x7FC00000u);        // a NaN in the window propagates
   else if (nwin & 1) med = key_f32(A);
   else {
-    // upper middle: A again if it occurs often enough, else the smallest key above A
-    const int cle = __popcll(__ballot(k0 <= A)) + __popcll(__ballot(k1 <= A));
-    unsigned m = 0xFFFFFFFFu;
-    if (k0 > A) m = k0;
-    if (k1 > A && k1 < m) m = k1;
-    for (int d2 = 32; d2 >= 1; d2 >>= 1) {
-      const unsigned o = __shfl_xor(m, d2);
-      if (o < m) m = o;
+    // upper middle: A again if it occurs often enough (impossible when A was alone in its interval), else the
+    // smallest key above A
+    bool again = false;
+    if (!single) again = __popcll(__ballot(k0 <= A)) + __popcll(__ballot(k1 <= A)) >= kt + 2;
+    unsigned B = A;
+    if (!again) {                                            // wave-uniform
+      unsigned m = (k0 > A) ? k0 : 0xFFFFFFFFu;
+      if (k1 > A && k1 < m) m = k1;
+      B = adsb_wave_min_u32(m);
     }
-    const unsigned B = (cle >= ((nwin - 1) >> 1) + 2) ? A : m;
     med = __fmul_rn(__fadd_rn(key_f32(A), key_f32(B)), 0.5f);          // f32(a+b)/2
   }
   const bool bitA = dem && x1 > x0, bitB = dem && lane < 48 && y1 > y0;                     // demod.py:95
   const unsigned long long ma = __ballot(bitA), mb = __ballot(bitB);
-  const unsigned pflags = parity_prefilter(ma, mb, pc);
   if (lane == 0) {
     const unsigned long long ra = __builtin_bswap64(__brevll(ma));
     const unsigned long long rb = __builtin_bswap64(__brevll(mb)) & 0xFFFFFFFFFFFFull;
-    const unsigned flags = (dem ? (kDemod | pflags) : 0u) | xflags;
+    const unsigned flags = (dem ? kDemod : 0u) | xflags;    // the tail adds kKept / kHead and the parity pre-filter bits
     Rec r;
     r.w[0] = (unsigned long long)offset;
     r.w[1] = (unsigned long long)__builtin_bit_cast(unsigned, peak) |
@@ -410,9 +413,46 @@ __device__ __forceinline__ void burst_reduce(long long offset, int nwin, bool va
   }
 }
 
+// Mode S parity pre-filter of one finished record (one THREAD per record, in the tail: k_compact), from its packed
+// bits: the same verdict as parity_prefilter above.  Syndrome = message polynomial mod G (decoder.py:693-714: CRC of
+// the first L-24 bits XOR the last 24), byte-wise with the 256-entry table of v(x) * x^24 mod G.
+struct Crc8Tab { unsigned t[256]; };
+constexpr Crc8Tab make_crc8_tab() {
+  Crc8Tab tab{};
+  for (unsigned v = 0; v < 256; ++v) {
+    unsigned c = v << 16;
+    for (int k = 0; k < 8; ++k) {
+      c <<= 1;
+      if (c & 0x1000000u) c ^= 0x1FFF409u;
+    }
+    tab.t[v] = c & 0xFFFFFFu;
+  }
+  return tab;
+}
+__device__ __forceinline__ unsigned parity_flags_of(unsigned long long w2, unsigned long long w3) {
+  static constexpr Crc8Tab tab = make_crc8_tab();
+  const unsigned df = (unsigned)(w2 & 0xFFu) >> 3;                                         // decoder.py:551
+  const unsigned dfb = 1u << df;
+  const bool lng = (dfb & kDfLongSet) != 0, known = lng || (dfb & kDfShortSet) != 0;
+  unsigned flags = df << kDfShift;
+  if (lng) flags |= kLongFmt;
+  if (known) flags |= kKnownDf;
+  if (dfb & kDfPiSet) {                                                                     // decoder.py:625,679
+    const int nb = lng ? 14 : 7;
+    unsigned crc = 0u, last = 0u;
+    for (int k = 0; k < nb; ++k) {
+      const unsigned byte = (unsigned)((k < 8 ? (w2 >> (8 * k)) : (w3 >> (8 * (k - 8)))) & 0xFFu);
+      if (k < nb - 3) crc = ((crc << 8) ^ tab.t[((crc >> 16) ^ byte) & 0xFFu]) & 0xFFFFFFu;
+      else last = (last << 8) | byte;
+    }
+    if ((crc ^ last) == 0u) flags |= kParityOk;
+  }
+  return flags;
+}
+
 // Record of a centre whose samples come from global memory (k_longrun: pulses longer than the LDS window).
 template <int MODE>
-__device__ void burst_finish(const DetectArgs& a, const BurstFetch<MODE>& f, Rec* out, int lane, const ParityConsts& pc) {
+__device__ void burst_finish(const DetectArgs& a, const BurstFetch<MODE>& f, Rec* out, int lane) {
   const long long n = a.n, p = f.p;
   const int sps = a.sps, half = sps >> 1;
   const bool dem = p + 119ll * sps + half < a.dem_hi;   // demod.py:76,82 (sps even)
@@ -443,7 +483,7 @@ __device__ void burst_finish(const DetectArgs& a, const BurstFetch<MODE>& f, Rec
     x1 = val(f.x1, s0); x0 = val(f.x0, s0 + half);
     y1 = val(f.y1, s1); y0 = val(f.y0, s1 + half);
   }
-  burst_reduce(a.origin + p, nwin, val0, val1, peak, v0, v1, dem, x1, x0, y1, y0, f.xflags, out, lane, pc);
+  burst_reduce(a.origin + p, nwin, val0, val1, peak, v0, v1, dem, x1, x0, y1, y0, f.xflags, out, lane);
 }
 
 // Record of a centre found by k_detect, built by the whole wavefront while the centre's tile is still in its LDS
@@ -451,32 +491,14 @@ __device__ void burst_finish(const DetectArgs& a, const BurstFetch<MODE>& f, Rec
 // window always lies inside it, the bit samples do for all of a 2 Msps burst that starts in the tile and for the
 // beginning of longer ones -- samples past the window come from global memory (they are the next thing this
 // wavefront streams anyway, so that fetch is served by the caches a moment later).  p = centre relative to t0.
-// Inlined into k_detect's match loop (ADSB_INLINE_RECORDS=1, the shipped form: 75 VGPRs, no call).  It can also be
-// built as a real call (=0: how it was introduced, when the streaming loop could not spare the registers); for that
-// form every input is passed by value -- a by-reference DetectArgs would force the kernel arguments into scratch
-// memory -- and the window arrives as a generic pointer.  A call costs the callee's entry wait for ALL outstanding
-// memory operations, i.e. for the prefetch of the next tile, once per match: measured 1.54 vs 1.48-1.52 ms per pass.
+// Inlined into k_detect's hit loop: a real call would cost the callee's entry wait for ALL outstanding memory
+// operations, i.e. for the prefetch of the next tile, once per hit.
 struct WinArgs {
   const void* data; long long n, in0_base, dem_hi, origin; float scale; int sps;
 };
-// s_x_generic: the window as a generic pointer (what crosses a real call); it is cast back to the LDS address space at
-// once, so the reads are ds_read (ordered by lgkmcnt) and not flat loads -- a flat load counts on vmcnt, and waiting for
-// it would also wait for the prefetch of the next tile, which is older and still in flight.  For the same reason the
-// parity masks arrive in registers (pc: loaded once per kernel) instead of being fetched here.
-#ifndef ADSB_INLINE_RECORDS
-#define ADSB_INLINE_RECORDS 1
-#endif
-#if ADSB_INLINE_RECORDS
-#define ADSB_RECORD_FN __forceinline__
-#else
-#define ADSB_RECORD_FN __attribute__((noinline))
-#endif
 template <int MODE>
-__device__ ADSB_RECORD_FN void burst_from_window(WinArgs a, const float* s_x_generic, long long t0, int p,
-                                                 unsigned xflags, Rec* out, int lane, unsigned long long pc_m1,
-                                                 unsigned long long pc_m2) {
-  const ParityConsts pc{pc_m1, pc_m2};
-  const ADSB_LDS float* s_x = (const ADSB_LDS float*)s_x_generic;
+__device__ __forceinline__ void burst_from_window(WinArgs a, const float* s_x, long long t0, int p, unsigned xflags,
+                                                  Rec* out, int lane) {
   const int sps = a.sps, half = sps >> 1;
   const long long P = t0 + p;
   long long wlo = P - kNoise;                                // framer.py:156: in0[max(0, pulse_idx-100) : pulse_idx]
@@ -501,179 +523,176 @@ __device__ ADSB_RECORD_FN void burst_from_window(WinArgs a, const float* s_x_gen
       if (lane < 48) { y1 = smp(j0 + 64 * sps); y0 = smp(j0 + 64 * sps + half); }
     }
   }
-  burst_reduce(a.origin + P, nwin, val0, val1, peak, v0, v1, dem, x1, x0, y1, y0, xflags, out, lane, pc);
-}
-
-// ---- global -> register -> LDS staging of one wavefront's share of a span ----------------------------
-// A span of COUNT samples is split into kWaves contiguous shares; each wavefront fetches its share with
-// 16-byte loads (1 KiB contiguous per wave instruction) into registers (span_issue) and later turns it
-// into |IQ|^2 floats in LDS AND into the natural-order threshold bitmask words of those samples
-// (span_commit) -- so the fetch of tile k+1 is in flight while tile k is processed, and the threshold
-// masks cost no LDS re-read.  The fast path (whole span inside the buffer) has no per-load branches.
-// One wave-wide 16-byte (8-byte for the 8-bit formats) load of the stream, marked non-temporal (`global_load ... nt`):
-// every sample is fetched exactly once, so it should not displace anything in the caches on its way.  Measured on
-// MI355X, 2^30 complex64 samples per pass, three passes in flight: 1.51-1.54 ms per pass with nt against 1.63-1.64
-// with the default policy (k_detect alone 1.54-1.57 against 1.62-1.63).  The includer provides adsb_ld_stream<V>().
-template <class Q>
-__device__ __forceinline__ Q ld_stream(const char* p) {
-  return adsb_ld_stream<Q>(p);
-}
-template <bool IQ8> struct SelectQ { using type = float4; };
-template <> struct SelectQ<true> { using type = float2; };
-template <int MODE, int COUNT, int NWAVES = kWaves>
-struct Span {
-  static constexpr int PER = (MODE == 0) ? 2 : 4;             // samples per lane load (complex64: 2 in 16 B; float / int16 IQ: 4 in 16 B; int8 IQ: 4 in 8 B)
-  static constexpr int SHARE = COUNT / NWAVES;                // samples per wavefront (NWAVES share the span)
-  static constexpr int GROUP = 64 * PER;                      // samples per wave-wide load
-  static constexpr int ITER = (SHARE + GROUP - 1) / GROUP;    // (a partial last group only for the head span)
-  static constexpr int LANES = (SHARE < GROUP) ? SHARE / PER : 64;   // active lanes when SHARE < GROUP
-  using Q = typename SelectQ<mode_is_iq8(MODE)>::type;
-  Q q[ITER];
-};
-
-// Returns false (wave- and block-uniform) when the span is not entirely inside the buffer: the caller
-// then stages it with span_fill_ragged instead (at most one tile per call ends ragged).
-template <int MODE, int COUNT, int NWAVES>
-__device__ __forceinline__ bool span_issue(Span<MODE, COUNT, NWAVES>& sp, const DetectArgs& a, long long src, int wave, int lane) {
-  using S = Span<MODE, COUNT, NWAVES>;
-  if (src + COUNT > a.n) return false;
-  // scalar base + 32-bit lane offset: one address VGPR for all loads of the span
-  const long long wsrc = src + (long long)wave * S::SHARE;
-  constexpr int BPS = mode_bytes(MODE);                       // bytes per sample
-  const char* ub = reinterpret_cast<const char*>(a.data) + wsrc * BPS;
-  using Q = typename S::Q;
-  const unsigned lo = (unsigned)lane * (unsigned)sizeof(Q);
-#pragma unroll
-  for (int k = 0; k < S::ITER; ++k) {
-    if (S::LANES == 64 || lane < S::LANES) sp.q[k] = ld_stream<Q>(ub + (k * 64 * (int)sizeof(Q) + lo));
-    else sp.q[k] = Q{};
-  }
-  return true;
-}
-
-// Slow path for the ragged end of the buffer: scalar reads (zeros past the end) straight into LDS, then the
-// mask words by ballot over LDS.  One wavefront stages its own span.
-template <int MODE, int COUNT>
-__device__ __forceinline__ void span_fill_ragged_w(float* sx, unsigned long long* smask, int dst,
-                                                   const DetectArgs& a, long long src, int lane) {
-  for (int i = lane; i < COUNT; i += 64) sx[dst + i] = xg<MODE>(a.data, a.n, src + i, a.scale);
-  adsb_wave_sync();
-  for (int w = 0; w < COUNT / 64; ++w) {
-    const unsigned long long m = __ballot(sx[dst + 64 * w + lane] >= a.thr);
-    if (lane == 0) smask[(dst >> 6) + w] = m;
-  }
-}
-
-// dst = LDS sample index of the span's first sample (multiple of 64).  Every lane of the wavefront
-// must call this (ballots); a wavefront whose share is one 64-sample word (the head span) uses only
-// its low lanes for data and writes one mask word.
-// REISSUE: `next` = address of this wavefront's share of the NEXT span (entirely inside the buffer); every
-// register is loaded again the moment its samples have been converted, so the only time a wavefront has no
-// fetch in flight is one |IQ|^2 computation per register -- not the whole commit (LDS writes, ballots, mask
-// interleave), which now runs under the next tile's loads.
-template <int MODE, int COUNT, int NWAVES, int REISSUE = 0>
-__device__ __forceinline__ void span_commit(Span<MODE, COUNT, NWAVES>& sp, float* sx, unsigned long long* smask,
-                                            int dst, float thr, float scale, int wave, int lane,
-                                            const char* next = nullptr) {
-  using S = Span<MODE, COUNT, NWAVES>;
-  using Q = typename S::Q;
-  const int wdst = dst + wave * S::SHARE;
-  const bool act = (S::LANES == 64) || lane < S::LANES;
-  const unsigned lo = (unsigned)lane * (unsigned)sizeof(Q);
-#pragma unroll
-  for (int k = 0; k < S::ITER; ++k) {
-    const int g = wdst + k * S::GROUP;                        // first LDS sample of this wave-wide group
-    if constexpr (MODE == 0) {
-      float2 m;
-      m.x = mag2f(sp.q[k].x, sp.q[k].y);
-      m.y = mag2f(sp.q[k].z, sp.q[k].w);
-      if (REISSUE > 0 && k < REISSUE) sp.q[k] = ld_stream<Q>(next + (k * 64 * (int)sizeof(Q) + lo));
-      if (act) *reinterpret_cast<float2*>(&sx[g + 2 * lane]) = m;
-      {
-        // lane l holds samples 2l, 2l+1: the even/odd threshold masks (framer.py:83-84) are interleaved into
-        // natural-order words on the SCALAR unit: s_bitreplicate doubles every bit, the masks pick the slot
-        const unsigned long long E = __ballot(act && m.x >= thr), O = __ballot(act && m.y >= thr);
-        const unsigned long long w0 = (adsb_bitrep32((unsigned)E) & 0x5555555555555555ull) |
-                                      (adsb_bitrep32((unsigned)O) & 0xAAAAAAAAAAAAAAAAull);
-        if (S::SHARE >= 128) {
-          const unsigned long long w1 = (adsb_bitrep32((unsigned)(E >> 32)) & 0x5555555555555555ull) |
-                                        (adsb_bitrep32((unsigned)(O >> 32)) & 0xAAAAAAAAAAAAAAAAull);
-          if (lane == 0) { smask[g >> 6] = w0; smask[(g >> 6) + 1] = w1; }
-        } else if (lane == 0) {
-          smask[g >> 6] = w0;
-        }
-      }
-    } else {
-      float4 m;
-      if constexpr (mode_is_iq8(MODE)) {                      // 8 int8 -> 4 |IQ|^2
-        const unsigned u0 = __builtin_bit_cast(unsigned, sp.q[k].x), u1 = __builtin_bit_cast(unsigned, sp.q[k].y);
-        m.x = mag2_iq8<MODE>(u0 & 0xFFFFu, scale);
-        m.y = mag2_iq8<MODE>(u0 >> 16, scale);
-        m.z = mag2_iq8<MODE>(u1 & 0xFFFFu, scale);
-        m.w = mag2_iq8<MODE>(u1 >> 16, scale);
-      } else if constexpr (MODE == 2) {                       // 8 int16 -> 4 |IQ|^2
-        m.x = mag2_iq16(__builtin_bit_cast(unsigned, sp.q[k].x), scale);
-        m.y = mag2_iq16(__builtin_bit_cast(unsigned, sp.q[k].y), scale);
-        m.z = mag2_iq16(__builtin_bit_cast(unsigned, sp.q[k].z), scale);
-        m.w = mag2_iq16(__builtin_bit_cast(unsigned, sp.q[k].w), scale);
-      } else {
-        m = sp.q[k];
-      }
-      if (REISSUE > 0 && k < REISSUE) sp.q[k] = ld_stream<Q>(next + (k * 64 * (int)sizeof(Q) + lo));
-      if (act) *reinterpret_cast<float4*>(&sx[g + 4 * lane]) = m;
-      {
-        const unsigned long long A = __ballot(act && m.x >= thr), B = __ballot(act && m.y >= thr);
-        const unsigned long long C = __ballot(act && m.z >= thr), D = __ballot(act && m.w >= thr);
-        const int c = lane & 3;
-        const unsigned long long sel = (c == 0) ? A : (c == 1) ? B : (c == 2) ? C : D;
-        const int sh = lane >> 2;
-        const unsigned long long w0 = __ballot((sel >> sh) & 1ull);
-        if (lane == 0) smask[g >> 6] = w0;
-        if (S::SHARE >= 256) {
-          const unsigned long long w1 = __ballot((sel >> (16 + sh)) & 1ull);
-          const unsigned long long w2 = __ballot((sel >> (32 + sh)) & 1ull);
-          const unsigned long long w3 = __ballot((sel >> (48 + sh)) & 1ull);
-          if (lane == 0) { smask[(g >> 6) + 1] = w1; smask[(g >> 6) + 2] = w2; smask[(g >> 6) + 3] = w3; }
-        }
-      }
-    }
-  }
-  if constexpr (REISSUE > 0) {                               // the registers consumed last are reloaded last
-#pragma unroll
-    for (int k = REISSUE; k < S::ITER; ++k) sp.q[k] = ld_stream<Q>(next + (k * 64 * (int)sizeof(Q) + lo));
-  }
+  burst_reduce(a.origin + P, nwin, val0, val1, peak, v0, v1, dem, x1, x0, y1, y0, xflags, out, lane);
 }
 
 // ---- k_detect: the streaming kernel, one independent stream segment per WAVEFRONT -------------------
-// Each wavefront ("unit" = blockIdx*4 + wave) walks its own contiguous chunk of the stream tile by tile with
-// its own sliding LDS window (kWTile + kFwd |IQ|^2 floats and their threshold mask words: the forward halo
-// of one tile is the head of the next, so every sample is fetched from HBM exactly once), its own rise list
-// and its own output list.  Nothing is shared between the wavefronts of a workgroup: there is no workgroup
-// barrier, and a wavefront that meets a burst does not hold up three others (a first version with four
-// wavefronts sharing a 4096-sample tile and three barriers per tile was 5 % slower).  a.chunk is the chunk of
-// ONE unit (multiple of kWTile); matched centres are appended to the unit's slice of `cands` in stream order;
-// ordering across units is by unit index (k_scan / k_gather).
+// Each wavefront ("unit" = blockIdx*4 + wave) walks its own contiguous chunk of the stream tile by tile (kWTile
+// samples) with its own sliding LDS window s_x[-kBack .. kWWin) of |IQ|^2 floats (the forward halo of one tile is
+// the head of the next, so every sample is fetched from HBM exactly once), its own threshold masks, rise list and
+// output list.  Nothing is shared between the wavefronts of a workgroup: there is no workgroup barrier.
+//
+// The kernel is bound by the number of instructions a wavefront issues per tile (measured: rate x instructions per
+// tile is the same for every input format), so the tile loop is built to issue as few as possible:
+//   * commit: 16-byte loads one tile ahead -> |IQ|^2 -> LDS, and the running integer maximum of the bit patterns (one
+//     v_max3 per two samples).  A body whose maximum stays below the threshold's bit pattern ("quiet": half of the
+//     tiles at 1 k bursts/s) costs nothing more than a zero written to its mask units.
+//   * only an active body pays for its threshold masks: lane l reads its 16 consecutive floats back from LDS and builds
+//     its own 16-bit mask (adsb_above4: compare + add-with-carry, 2 instructions per sample) -- mask unit u covers
+//     samples [16u, 16u+16) of the window; units are 16-bit halves of the dwords the fall search reads.
+//   * rises by 16-bit mask algebra per lane, the ordered rise list by a DPP prefix sum and a short per-lane loop that
+//     stores positions only; fall, centre and the 16 chip taps per rise with one lane per rise.
+//   * the tile counter and every per-tile condition are 32-bit scalars computed once per unit.
+constexpr int kUnit = 16;                        // samples per mask unit = one lane's share of a tile
+constexpr int kUnits = kWWin / kUnit;            // 80 units in the window
+constexpr int kTileUnits = kWTile / kUnit;       // 64: unit l of the tile belongs to lane l
+constexpr int kHeadUnits = kFwd / kUnit;         // 16 units of forward halo
+constexpr int kMaskDwords = kUnits / 2;          // the same masks read as 32-bit words
+static_assert(kTileUnits == 64 && kUnits % 2 == 0 && kFwd == 256 && kBack == 128, "lane <-> unit mapping and the slide copies");
+typedef unsigned short __attribute__((may_alias)) u16_alias;
+typedef unsigned __attribute__((may_alias)) u32_alias;
+
+// entries of the per-tile hit list (16 bits, written over the rise list in place)
+constexpr unsigned kHitValid = 0x8000u;          // matched centre: low 11 bits = centre relative to the tile
+constexpr unsigned kHitLongHint = 0x4000u;       // ... whose first data bit is set (long-aware gate only)
+constexpr unsigned kHitLongPulse = 0x2000u;      // a pulse that leaves the LDS window: low 11 bits = its RISE
+
+// The body of one tile (kWTile samples) in flight between HBM and LDS: ITER 16-byte loads per lane, 1 KiB contiguous
+// per wave instruction; lane l's load k holds samples k*64*SPL + SPL*l ... (+SPL) of the body.
 template <int MODE>
-__global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs a) {
+struct Body {
+  static constexpr int BPS = mode_bytes(MODE);
+  static constexpr int ITER = kWTile * BPS / 1024;          // complex64: 8, float / int16 IQ: 4, 8-bit IQ: 2
+  static constexpr int SPL = 16 / BPS;                       // samples per lane and load: 2 / 4 / 8
+  float4 q[ITER];
+};
+
+template <int MODE>
+__device__ __forceinline__ void body_issue(Body<MODE>& b, const char* src, int lane) {
+  const unsigned lo = (unsigned)lane * 16u;                   // scalar base + one 32-bit lane offset
+#pragma unroll
+  for (int k = 0; k < Body<MODE>::ITER; ++k) b.q[k] = adsb_ld_stream<float4>(src + (k * 1024 + lo));
+}
+
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imax3(int a, int b, int c) { return imax(imax(a, b), c); }     // v_max3_i32
+
+// |IQ|^2 of the SPL samples of one 16-byte load (each format's exact arithmetic, see mag2f / mag2_iq16 / mag2_iq8)
+template <int MODE>
+__device__ __forceinline__ void body_convert(const float4& q, float scale, float* m) {
+  if constexpr (MODE == 0) {
+    m[0] = mag2f(q.x, q.y);
+    m[1] = mag2f(q.z, q.w);
+  } else if constexpr (MODE == 1) {
+    m[0] = q.x; m[1] = q.y; m[2] = q.z; m[3] = q.w;
+  } else if constexpr (MODE == 2) {
+    m[0] = mag2_iq16(__builtin_bit_cast(unsigned, q.x), scale);
+    m[1] = mag2_iq16(__builtin_bit_cast(unsigned, q.y), scale);
+    m[2] = mag2_iq16(__builtin_bit_cast(unsigned, q.z), scale);
+    m[3] = mag2_iq16(__builtin_bit_cast(unsigned, q.w), scale);
+  } else {
+    const unsigned u[4] = {__builtin_bit_cast(unsigned, q.x), __builtin_bit_cast(unsigned, q.y),
+                           __builtin_bit_cast(unsigned, q.z), __builtin_bit_cast(unsigned, q.w)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      m[2 * j] = mag2_iq8<MODE>(u[j] & 0xFFFFu, scale);
+      m[2 * j + 1] = mag2_iq8<MODE>(u[j] >> 16, scale);
+    }
+  }
+}
+
+// Registers -> |IQ|^2 floats at sx_body[0 .. kWTile) (= s_x + kFwd); returns the lane's maximum over the BIT PATTERNS
+// of its samples as signed integers: for a threshold > 0, "no sample of the body >= thr" <=> every lane's maximum is
+// below the threshold's bit pattern (non-negative floats order like their bits; negative values and -0.0 are negative
+// integers; a NaN with the sign clear is larger than everything and only sends the body down the exact path).
+// REISSUE: every register is loaded again from `next` (this wavefront's next body, entirely inside the buffer) the
+// moment its samples have been converted.
+template <int MODE, bool REISSUE>
+__device__ __forceinline__ int body_commit(Body<MODE>& b, float* sx_body, float scale, int lane, const char* next) {
+  using B = Body<MODE>;
+  int mx = (int)0x80000000u;
+  const unsigned lo = (unsigned)lane * 16u;
+#pragma unroll
+  for (int k = 0; k < B::ITER; ++k) {
+    float m[B::SPL];
+    body_convert<MODE>(b.q[k], scale, m);
+    if (REISSUE) b.q[k] = adsb_ld_stream<float4>(next + (k * 1024 + lo));
+    float* dst = sx_body + (k * 64 * B::SPL + B::SPL * lane);
+    if constexpr (B::SPL == 2) {
+      *reinterpret_cast<float2*>(dst) = float2{m[0], m[1]};
+      mx = imax3(mx, __builtin_bit_cast(int, m[0]), __builtin_bit_cast(int, m[1]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < B::SPL; j += 4) {
+        *reinterpret_cast<float4*>(dst + j) = float4{m[j], m[j + 1], m[j + 2], m[j + 3]};
+        mx = imax3(mx, __builtin_bit_cast(int, m[j]), __builtin_bit_cast(int, m[j + 1]));
+        mx = imax3(mx, __builtin_bit_cast(int, m[j + 2]), __builtin_bit_cast(int, m[j + 3]));
+      }
+    }
+  }
+  return mx;
+}
+
+// The 16-bit threshold mask (framer.py:83-84) of the 16 consecutive floats at p (16-byte aligned): bit k <-> p[k].
+__device__ __forceinline__ unsigned unit_mask(const float* p, float thr) {
+  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+  const float4 c = reinterpret_cast<const float4*>(p)[2], d = reinterpret_cast<const float4*>(p)[3];
+  unsigned acc = 0;
+  acc = adsb_above4(acc, d.w, d.z, d.y, d.x, thr);
+  acc = adsb_above4(acc, c.w, c.z, c.y, c.x, thr);
+  acc = adsb_above4(acc, b.w, b.z, b.y, b.x, thr);
+  acc = adsb_above4(acc, a.w, a.z, a.y, a.x, thr);
+  return acc;
+}
+
+// The 16-chip preamble test (framer.py:137-147) for a centre whose taps all lie in the LDS window: chip k is
+// tp[k*half] > tp[0]/2 and the chips must spell 1010000101000000.  Chips 0, 2, 7, 9 are compared one by one (a NaN
+// tap fails); the twelve others must all be "not above", i.e. their maximum is not above: five v_max3 and one v_max
+// (a NaN among them counts as a low chip and is skipped by the maximum, which is the same thing) and ONE compare.
+// HALF > 0: samples per chip known at compile time -- the taps become ds_read2_b32 with immediate offsets.
+template <int HALF>
+__device__ __forceinline__ bool chips_match(const float* tp, int half_rt) {
+  const int h = HALF ? HALF : half_rt;
+  float tap[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tap[k] = tp[k * h];
+  const float hp = __fmul_rn(tap[0], 0.5f);                  // tap 0 IS in0[pulse_idx]; /2 is exact
+  const bool hi = (tap[0] > hp) & (tap[2] > hp) & (tap[7] > hp) & (tap[9] > hp);
+  float mx = adsb_fmax3(tap[1], tap[3], tap[4]);
+  mx = adsb_fmax3(mx, tap[5], tap[6]);
+  mx = adsb_fmax3(mx, tap[8], tap[10]);
+  mx = adsb_fmax3(mx, tap[11], tap[12]);
+  mx = adsb_fmax3(mx, tap[13], tap[14]);
+  mx = adsb_fmax3(mx, tap[15], tap[15]);
+  return hi & !(mx > hp);
+}
+
+// HALF = samples per chip (sps/2) when it is one of the instantiated rates (2, 4, 8, 20 Msps), else 0 = run-time value.
+template <int MODE, int HALF>
+__global__ void __launch_bounds__(kThreads, kMinWaves) k_detect(DetectArgs a) {
   __shared__ __attribute__((aligned(16))) float s_xa[kWaves][kBack + kWWin];
-  __shared__ unsigned long long s_maska[kWaves][kWWords];
-  __shared__ unsigned s_risea[kWaves][kWTile / 2];
+  __shared__ __attribute__((aligned(16))) unsigned s_ma[kWaves][kMaskDwords];
+  __shared__ __attribute__((aligned(4))) unsigned short s_risea[kWaves][kWTile / 2];
 
   const int lane = threadIdx.x & 63, wave = adsb_uniform((int)(threadIdx.x >> 6));
   float* s_x = s_xa[wave] + kBack;                           // s_x[j] <-> sample t0 + j, j in [-kBack, kWWin)
-  unsigned long long* s_mask = s_maska[wave];
-  unsigned* s_rise = s_risea[wave];
+  u32_alias* s_m32 = reinterpret_cast<u32_alias*>(s_ma[wave]);
+  u16_alias* s_m16 = reinterpret_cast<u16_alias*>(s_ma[wave]);     // unit u <-> samples [16u, 16u + 16) of the window
+  u16_alias* s_rise = reinterpret_cast<u16_alias*>(s_risea[wave]);
   const long long unit = (long long)blockIdx.x * kWaves + wave;
   const long long c0 = unit * a.chunk;
   long long c1 = c0 + a.chunk;
   if (c1 > a.scan_hi) c1 = a.scan_hi;
-  const int half = a.sps >> 1;
-  long long lastp_g = kNoIndex;
+  const int half = HALF ? HALF : (a.sps >> 1);
   int nrec = 0;                                              // wave-uniform running count of this unit's list
   unsigned uflags = 0u;
+  int lp = -1;                                               // per lane: largest paired pulse centre so far, relative to c0
   int pred = adsb_uniform(above_at<MODE>(a, c0 - 1) ? 1 : 0);
   unsigned long long* my_cands = a.cands + unit * a.rec_cap;
   Rec* my_recs = a.recs + unit * a.rec_cap;
+  const float thr = a.thr;
+  const bool thr_pos = thr > 0.0f;                           // else (thr <= 0 or NaN): every body takes the exact path
+  const int thr_bits = __builtin_bit_cast(int, thr);
 
   // virtual rise in the zero history in front of a fresh stream: only possible when 0 >= thr
   if (unit == 0 && a.scan_lo < 0 && (0.0f >= a.thr) && !(a.prev_in0 >= a.thr)) {
@@ -686,264 +705,221 @@ __global__ void __launch_bounds__(kThreads, ADSB_MIN_WAVES) k_detect(DetectArgs 
     nrec = 1;
   }
 
-  Span<MODE, kWTile, 1> body;
-  bool body_ok = true;
+  // Tile counters of this unit (32-bit, wave-uniform), computed once: tile `it` covers [c0 + it*kWTile, +kWTile).
+  //   it < it_re   : the NEXT tile's body lies inside the buffer and is needed -> reload every register as it is consumed
+  //   it_i0 <= it < it_i1 : "interior": the whole tile is owned ([scan_lo, scan_hi)) and the window ends in front of
+  //                  fall_hi -> no per-lane 64-bit ownership / end-of-call arithmetic
+  constexpr int BPS = mode_bytes(MODE);
+  int ntile = 0, it_re = 0, it_i0 = 0, it_i1 = 0;
   if (c0 < c1) {
-    Span<MODE, kFwd, 1> head;
-    const bool head_ok = span_issue(head, a, c0, 0, lane);
-    body_ok = span_issue(body, a, c0 + kFwd, 0, lane);
-    if (head_ok) span_commit(head, s_x, s_mask, 0, a.thr, a.scale, 0, lane);
-    else span_fill_ragged_w<MODE, kFwd>(s_x, s_mask, 0, a, c0, lane);
-    // back halo of the first tile (later tiles inherit it from their predecessor): once per unit and launch
-    for (int i = lane; i < kBack; i += 64) s_x[i - kBack] = xg<MODE>(a.data, a.n, c0 - kBack + i, a.scale);
+    auto tiles_below = [](long long x) -> long long {          // number of it >= 0 with it*kWTile < x
+      return x <= 0 ? 0 : (x + kWTile - 1) / kWTile;
+    };
+    auto clampi = [](long long v, long long hi) -> int { return (int)(v < 0 ? 0 : (v > hi ? hi : v)); };
+    const long long nt = tiles_below(c1 - c0);
+    ntile = (int)nt;
+    // c0 + it*T + T < c1  and  c0 + it*T + 2T + kFwd <= n
+    long long re = tiles_below(c1 - c0 - kWTile);
+    const long long re2 = tiles_below(a.n - c0 - 2 * kWTile - kFwd + 1);
+    if (re2 < re) re = re2;
+    it_re = clampi(re, nt);
+    // scan_lo <= c0 + it*T,  c0 + it*T + T <= scan_hi,  c0 + it*T + kWWin < fall_hi
+    const long long i0 = tiles_below(a.scan_lo - c0);
+    long long i1 = tiles_below(a.scan_hi - c0 - kWTile + 1);
+    const long long i1f = tiles_below(a.fall_hi - c0 - kWWin);
+    if (i1f < i1) i1 = i1f;
+    it_i0 = clampi(i0, nt);
+    it_i1 = clampi(i1, nt);
   }
+  ntile = adsb_uniform(ntile); it_re = adsb_uniform(it_re); it_i0 = adsb_uniform(it_i0); it_i1 = adsb_uniform(it_i1);
+
+  Body<MODE> body;
+  bool body_ok = false;
+  if (ntile > 0) {
+    // head of the window and back halo of the first tile (later tiles inherit both): once per unit and launch
+    for (int i = lane; i < kBack + kFwd; i += 64) s_x[i - kBack] = xg<MODE>(a.data, a.n, c0 - kBack + i, a.scale);
+    adsb_wave_sync();
+    s_m16[lane & (kHeadUnits - 1)] = (unsigned short)unit_mask(s_x + kUnit * (lane & (kHeadUnits - 1)), thr);
+    body_ok = c0 + kFwd + kWTile <= a.n;
+    if (body_ok) body_issue(body, reinterpret_cast<const char*>(a.data) + (c0 + kFwd) * (long long)BPS, lane);
+  }
+  bool prev_active = true;                                   // the head units were computed exactly
+  const char* nb = reinterpret_cast<const char*>(a.data) + (c0 + kWTile + kFwd) * (long long)BPS;   // next tile's body
 
   const int lane_outer = lane;
-  const ParityConsts pc = parity_consts(lane);               // four registers for the whole kernel, see burst_from_window
-  for (long long t0 = c0; t0 < c1; t0 += kWTile) {
-    // The lane number through an opaque copy, renewed every tile: otherwise a dozen lane-derived addresses and masks
-    // (64-bit offsets of the loads, LDS addresses, 64*j + lane ...) are hoisted out of this loop as loop-invariant
-    // registers, which the 96-VGPR budget of five resident wavefronts per SIMD cannot hold (they were spilled to
-    // scratch memory, and every reload waited for the prefetch of the next tile with it).
+  for (int it = 0; it < ntile; ++it) {
+    // The lane number through an opaque copy, renewed every tile: otherwise lane-derived addresses are hoisted out of
+    // this loop as loop-invariant registers, which the register budget of five wavefronts per SIMD cannot hold.
     const int lane = adsb_opaque(lane_outer);
-    // -- A: commit this tile's body (floats + mask words 4..19), start fetching the next one
+    const long long t0 = c0 + (long long)it * kWTile;          // (only the rare paths below use it)
+    // -- A: commit this tile's body (floats to s_x[kFwd ..)), start fetching the next one
+    bool active;
     if (!body_ok) {
-      span_fill_ragged_w<MODE, kWTile>(s_x, s_mask, kFwd, a, t0 + kFwd, lane);
-      if (t0 + kWTile < c1) body_ok = span_issue(body, a, t0 + kWTile + kFwd, 0, lane);
-    } else if (kEarlyIssue > 0 && t0 + kWTile < c1 && t0 + 2 * kWTile + kFwd <= a.n) {
-      // the usual case: the next tile's body lies inside the buffer -> reload every register as soon as it is consumed
-      const char* nb = reinterpret_cast<const char*>(a.data) + (t0 + kWTile + kFwd) * (long long)mode_bytes(MODE);
-      span_commit<MODE, kWTile, 1, kEarlyIssue>(body, s_x, s_mask, kFwd, a.thr, a.scale, 0, lane, nb);
+      // ragged end of the buffer (at most the last two tiles of a call): scalar reads, zeros past the end
+      for (int i = lane; i < kWTile; i += 64) s_x[kFwd + i] = xg<MODE>(a.data, a.n, t0 + kFwd + i, a.scale);
+      active = true;
+      if (it + 1 < ntile && t0 + 2 * kWTile + kFwd <= a.n) { body_issue(body, nb, lane); body_ok = true; }
     } else {
-      span_commit(body, s_x, s_mask, kFwd, a.thr, a.scale, 0, lane);
-      if (t0 + kWTile < c1) body_ok = span_issue(body, a, t0 + kWTile + kFwd, 0, lane);
+      int mx;
+      if (it < it_re) {
+        mx = body_commit<MODE, true>(body, s_x + kFwd, a.scale, lane, nb);
+      } else {
+        mx = body_commit<MODE, false>(body, s_x + kFwd, a.scale, lane, nb);
+        body_ok = false;                                     // (it + 1 < ntile implies the next body is ragged)
+      }
+      active = !thr_pos || __ballot(mx >= thr_bits) != 0ull;
     }
+    nb += (long long)kWTile * BPS;
+    adsb_wave_sync();
+    // mask units of the body (units kHeadUnits .. kUnits): lane l owns body unit l
+    unsigned bm = 0u;
+    if (active) bm = unit_mask(s_x + kFwd + kUnit * lane, thr);      // wave-uniform branch
+    s_m16[kHeadUnits + lane] = (unsigned short)bm;
     adsb_wave_sync();
 
-    // -- B.1 rises / falls by mask algebra (framer.py:91-93)
-#if ADSB_RISE_BY_LANE
-    // lane l owns samples [16 l, 16 l + 16) of the tile: its 16 bits of the threshold mask and the bit in front of them
-    const int w = lane >> 2, sh16 = (lane & 3) << 4;
-    const unsigned long long Mw = s_mask[w];
-    const unsigned pbit = sh16 ? ((unsigned)(Mw >> (sh16 - 1)) & 1u)
-                               : (w ? (unsigned)(s_mask[w - 1] >> 63) : (unsigned)pred);
-    const unsigned m16 = (unsigned)(Mw >> sh16) & 0xFFFFu;
-    const long long sbase = t0 + 16ll * lane;
-    const unsigned own16 = (unsigned)bit_range(a.scan_lo - sbase, a.scan_hi - sbase) & 0xFFFFu;
-    const unsigned prev16 = (m16 << 1) | pbit;
-    unsigned piece = m16 & ~prev16 & own16;                 // rises among my 16 samples
-    const unsigned long long anyr = __ballot(piece != 0u), anyf = __ballot((~m16 & prev16 & own16) != 0u);
-#else
-    // lanes 0..15 own one word each
-    const int word = (lane < kWWords) ? lane : 0;          // lanes 0..19 hold words 0..19 (16..19 = forward halo)
-    const unsigned long long M = s_mask[word];
-    const unsigned long long pb = (word > 0) ? (s_mask[word - 1] >> 63) : (unsigned long long)pred;
-    const unsigned long long sh = (M << 1) | pb;
-    const long long wbase = t0 + 64ll * word;
-    const unsigned long long own = (lane < 16) ? bit_range(a.scan_lo - wbase, a.scan_hi - wbase) : 0ull;
-    unsigned long long R = M & ~sh & own;
-    const unsigned long long Fm = ~M & sh & own;
-    const unsigned long long anyr = __ballot(R != 0ull), anyf = __ballot(Fm != 0ull);
-#endif
-    uflags |= (anyr ? 1u : 0u) | (anyf ? 2u : 0u);
-    int nm = 0;
-    if (anyr) {                                            // wave-uniform: quiet stretches skip everything below
-      // Ordered rise list.  Each entry carries the rise index and, when the pulse ends within this or the next mask
-      // word (always, for real Mode-S pulses), its fall index -- found here from the mask words, which saves B.2 a
-      // dependent LDS round trip; 0xFFFF = not found yet (B.2 searches the LDS mask words).
-#if ADSB_RISE_BY_LANE
-      // Lane l extracts the rises among its samples [16 l, 16 l + 16) of the tile (`piece`, at most 8: a rise needs a
-      // sub-threshold sample in front of it) in a short per-lane loop; its slots
-      // follow from an exclusive prefix sum of the per-lane counts, built from four ballots (the counts have 4 bits).
-      // The instruction count follows the densest 16 samples of the tile instead of the number of non-empty mask
-      // words x a fixed cost: 2-3x fewer instructions on a tile that holds a 2 Msps burst, 6-8x fewer on 8 Msps dense
-      // traffic, where every word has rises.
-      int nr = 0;
-      {
-        const unsigned long long Mn = s_mask[w + 1];                            // w + 1 <= 16: a forward-halo word
-        const int cnt = __builtin_popcount(piece);
-        int slot = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const unsigned long long bm = __ballot(((cnt >> b) & 1) != 0);
-          slot += lanes_below(bm, lane) << b;
-          nr += __popcll(bm) << b;
-        }
+    // -- B: rises among the tile's own samples (units 0 .. 63); a tile can hold one only if this or the previous body
+    //       had a sample above the threshold (or the sample in front of the tile was)
+    int keepp = 0;
+    if (active || prev_active || pred) {
+      const bool interior = it >= it_i0 && it < it_i1;
+      // -- B.1 rises / falls by mask algebra (framer.py:91-93): lane l owns samples [16 l, 16 l + 16)
+      const unsigned W = (unsigned)s_m16[lane] | ((unsigned)s_m16[lane + 1] << 16);   // own unit, and the next one
+      const unsigned pW = adsb_lane_up1(W, (unsigned)pred << 15);
+      const unsigned m16 = W & 0xFFFFu, prev16 = ((m16 << 1) | ((pW >> 15) & 1u)) & 0xFFFFu;
+      unsigned own16 = 0xFFFFu;
+      if (!interior) {
+        const long long sbase = t0 + 16ll * lane;
+        own16 = (unsigned)bit_range(a.scan_lo - sbase, a.scan_hi - sbase) & 0xFFFFu;
+      }
+      unsigned piece = m16 & ~prev16 & own16;                 // rises among my 16 samples
+      const unsigned long long anyr = __ballot(piece != 0u), anyf = __ballot((~m16 & prev16 & own16) != 0u);
+      keepp = (adsb_readlane((int)W, 63) >> 15) & 1;
+      uflags |= (anyr ? 1u : 0u) | (anyf ? 2u : 0u);
+      if (anyr) {                                            // wave-uniform
+        // Ordered rise list: the slots of a lane follow from the prefix sum of the per-lane counts; every lane then
+        // stores the positions of its (at most 8) rises in a short loop.
+        const unsigned cnt = (unsigned)__builtin_popcount(piece);
+        const unsigned incl = adsb_wave_incl_scan(cnt);
+        const int nr = adsb_readlane((int)incl, 63);
+        unsigned slot = incl - cnt;
         while (piece) {
-          const int pos = sh16 + __builtin_ctz(piece);
+          s_rise[slot++] = (unsigned short)(kUnit * lane + __builtin_ctz(piece));
           piece &= piece - 1u;
-          const unsigned long long inv0 = (pos == 63) ? 0ull : (~Mw & (~0ull << (pos + 1)));
-          unsigned f = 0xFFFFu;
-          if (inv0) f = (unsigned)(64 * w + __builtin_ctzll(inv0));
-          else if (~Mn) f = (unsigned)(64 * (w + 1) + __builtin_ctzll(~Mn));
-          s_rise[slot++] = (unsigned)(64 * w + pos) | (f << 16);
         }
-      }
-#else
-      // word by word (wave-uniform loop over the 16 words, empty ones skipped): lane l takes bit l of the word and
-      // its slot from the prefix popcount
-      const int rlo = (int)(unsigned)R, rhi = (int)(unsigned)(R >> 32);
-      const int mlo = (int)(unsigned)M, mhi = (int)(unsigned)(M >> 32);
-      int nr = 0;
-#pragma unroll
-      for (int j = 0; j < kWOwn; ++j) {
-        const unsigned long long Rj = (unsigned long long)(unsigned)adsb_readlane(rlo, j) |
-                                      ((unsigned long long)(unsigned)adsb_readlane(rhi, j) << 32);
-        if (Rj) {
-          const unsigned long long Mj = (unsigned long long)(unsigned)adsb_readlane(mlo, j) |
-                                        ((unsigned long long)(unsigned)adsb_readlane(mhi, j) << 32);
-          const unsigned long long Mn = (unsigned long long)(unsigned)adsb_readlane(mlo, j + 1) |
-                                        ((unsigned long long)(unsigned)adsb_readlane(mhi, j + 1) << 32);
-          if ((Rj >> lane) & 1ull) {
-            const unsigned long long inv0 = (lane == 63) ? 0ull : (~Mj & (~0ull << (lane + 1)));
-            unsigned f = 0xFFFFu;
-            if (inv0) f = (unsigned)(64 * j + __builtin_ctzll(inv0));
-            else if (~Mn) f = (unsigned)(64 * (j + 1) + __builtin_ctzll(~Mn));
-            s_rise[nr + lanes_below(Rj, lane)] = (unsigned)(64 * j + lane) | (f << 16);
-          }
-          nr += __popcll(Rj);
-        }
-      }
-#endif
-      adsb_wave_sync();
+        adsb_wave_sync();
 
-      // -- B.2 per rise: fall, centre, 16-chip test (framer.py:113,137-147)
-      int lp = -1, lp2 = -1, hflag = 0;
-      for (int i = lane; i < nr; i += 64) {
-        const unsigned e0 = s_rise[i];
-        const int r = (int)(e0 & 0xFFFFu);
-        int f = (int)(e0 >> 16);
-        if (f == 0xFFFF) {                                 // run longer than a word: search the LDS mask words
-          int w = (r >> 6) + 2;
-          unsigned long long inv = 0ull;
-          while (w < kWWords && (inv = ~s_mask[w]) == 0ull) ++w;
-          f = (w < kWWords) ? w * 64 + __builtin_ctzll(inv) : -1;
-        }
-        unsigned res = 0;
-        if (f < 0) {
-          if (t0 + kWWin < a.fall_hi) res = 0xFFFFu;       // pulse longer than the window: k_longrun
-          else if (!a.end_is_call_end) hflag = 4;
-        } else if (t0 + f < a.fall_hi) {
-          const int p = (r + f) >> 1;                      // framer.py:113
-          if (i == nr - 1) lp = p;                         // centres increase with i; only the last rise of
-          else if (i == nr - 2) lp2 = p;                   // a tile can be left without a fall
-          // 16-chip test as a chain of booleans: a per-lane boolean is a lane mask in scalar registers, so every chip
-          // costs one vector compare and one scalar AND (assembling a 16-bit chip word per lane cost three vector
-          // instructions per chip)
-          bool match = true;
-          if (p + 15 * half < kWWin) {                // all 16 taps inside the LDS window: one LDS round trip
-            const float* tp = s_x + p;
-            float tap[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) tap[k] = tp[k * half];
-            const float hp = __fmul_rn(tap[0], 0.5f);      // tap 0 IS in0[pulse_idx]; /2 is exact
-#pragma unroll
-            for (int k = 0; k < 16; ++k) match = match & ((tap[k] > hp) == (((kTemplate >> k) & 1u) != 0u));   // framer.py:140-147
-          } else {                                         // rare: taps past the window come from global memory
-            const float hp = __fmul_rn(s_x[p], 0.5f);
-            unsigned chips = 0;
+        // -- B.2 one lane per rise: fall, centre, 16-chip test (framer.py:113,137-147); hits are compacted in order
+        //    over the rise list in place (a hit's slot never lies beyond its rise's)
+        int nm = 0;
+        bool hflag = false;
+        const int trel = it * kWTile;
+        for (int base = 0; base < nr; base += 64) {
+          const int i = base + lane;
+          unsigned res = 0u;
+          if (i < nr) {
+            const int r = (int)s_rise[i];
+            // the first sub-threshold sample after r: 32 mask bits from r on (two aligned words), else word by word
+            const int d = r >> 5, sh = r & 31;
+            const unsigned long long two = ((unsigned long long)s_m32[d + 1] << 32) | s_m32[d];
+            const unsigned inv = ~(unsigned)(two >> sh);      // bit 0 (the rise itself) is clear
+            int f = -1;
+            if (inv) {
+              f = r + __builtin_ctz(inv);
+            } else {
+              int wd = d + 1;
+              unsigned cur = ~s_m32[wd] & (~0u << sh);
+              while (cur == 0u && ++wd < kMaskDwords) cur = ~s_m32[wd];
+              if (wd < kMaskDwords && cur) f = wd * 32 + __builtin_ctz(cur);
+            }
+            if (f < 0) {
+              if (interior || t0 + kWWin < a.fall_hi) res = kHitValid | kHitLongPulse | (unsigned)r;    // k_longrun
+              else if (!a.end_is_call_end) hflag = true;
+            } else if (interior || t0 + f < a.fall_hi) {
+              const int p = (r + f) >> 1;                    // framer.py:113
+              lp = imax(lp, trel + p);                        // (centres increase along the stream)
+              bool match = true;
+              if (p + 15 * half < kWWin) {                   // all 16 taps inside the LDS window: one LDS round trip
+                match = chips_match<HALF>(s_x + p, half);
+              } else {                                       // rare: taps past the window come from global memory
+                const float hp = __fmul_rn(s_x[p], 0.5f);
+                unsigned chips = 0;
 #pragma unroll 1
-            for (int k = 0; k < 16; ++k) {
-              const int idx = p + k * half;
-              const float v = (idx < kWWin) ? s_x[idx] : xg<MODE>(a.data, a.n, t0 + idx, a.scale);
-              chips |= (v > hp ? 1u : 0u) << k;
+                for (int k = 0; k < 16; ++k) {
+                  const int idx = p + k * half;
+                  const float v = (idx < kWWin) ? s_x[idx] : xg<MODE>(a.data, a.n, t0 + idx, a.scale);
+                  chips |= (v > hp ? 1u : 0u) << k;
+                }
+                match = chips == kTemplate;
+              }
+              if (match) {
+                res = kHitValid | (unsigned)p;
+                if (a.long_aware) {                          // first data bit (demod.py:87-95, k = 0): DF >= 16 = long reply
+                  const int i1 = p + 16 * half, i0 = i1 + half;
+                  const float v1 = (i1 < kWWin) ? s_x[i1] : xg<MODE>(a.data, a.n, t0 + i1, a.scale);
+                  const float v0 = (i0 < kWWin) ? s_x[i0] : xg<MODE>(a.data, a.n, t0 + i0, a.scale);
+                  if (v1 > v0) res |= kHitLongHint;
+                }
+              }
+            } else if (!a.end_is_call_end) {
+              hflag = true;
             }
-            match = chips == kTemplate;
           }
-          if (match) {
-            res = 0x8000u | (unsigned)p;
-            if (a.long_aware) {                              // first data bit (demod.py:87-95, k = 0): DF >= 16 = long reply
-              const int i1 = p + 16 * half, i0 = i1 + half;
-              const float v1 = (i1 < kWWin) ? s_x[i1] : xg<MODE>(a.data, a.n, t0 + i1, a.scale);
-              const float v0 = (i0 < kWWin) ? s_x[i0] : xg<MODE>(a.data, a.n, t0 + i0, a.scale);
-              if (v1 > v0) res |= 0x10000u;
-            }
+          const unsigned long long mb = __ballot(res != 0u);
+          if (mb) {                                          // wave-uniform
+            if (res) s_rise[nm + lanes_below(mb, lane)] = (unsigned short)res;
+            nm += __popcll(mb);
           }
-        } else if (!a.end_is_call_end) {
-          hflag = 4;
         }
-        s_rise[i] = res;
-      }
-      {
-        const unsigned long long m1 = __ballot(lp >= 0), m2 = __ballot(lp2 >= 0), mh = __ballot(hflag != 0);
-        const int v1 = __shfl(lp, m1 ? __builtin_ctzll(m1) : 0);
-        const int v2 = __shfl(lp2, m2 ? __builtin_ctzll(m2) : 0);
-        const int wl = m1 ? v1 : (m2 ? v2 : -1);
-        if (wl >= 0) lastp_g = t0 + wl;
-        if (mh) uflags |= 4u;
-      }
-      adsb_wave_sync();
+        if (!interior && __ballot(hflag)) uflags |= 4u;
+        adsb_wave_sync();
 
-      // -- B.3 ordered in-place compaction of the matched centres
-      for (int base = 0; base < nr; base += 64) {
-        const int i = base + lane;
-        const unsigned e = (i < nr) ? s_rise[i] : 0u;
-        const unsigned long long mb = __ballot(e != 0);
-        if (e) s_rise[nm + lanes_below(mb, lane)] = e;
-        nm += __popcll(mb);
-      }
-      adsb_wave_sync();
-
-      // -- C: this tile's matches, in stream order: the list word and, built by the whole wavefront from the LDS
-      //    window while it still holds the burst's samples, the burst record (wave-uniform loop: a tile rarely has
-      //    more than one or two matches)
-      for (int m = 0; m < nm; ++m) {
-        const int slot = nrec + m;
-        if (slot >= a.rec_cap) break;                        // overflow: reported through the count, call is re-run
-        const unsigned e = (unsigned)adsb_uniform((int)s_rise[m]);
-        if (e == 0xFFFFu) {
-          if (lane == 0) {
-            // the long pulse is the last rise of its tile: recover its index from the masks
-            long long rg = kNoIndex;
-            for (int w2 = kWOwn - 1; w2 >= 0 && rg == kNoIndex; --w2) {
-              const unsigned long long M2 = s_mask[w2];
-              const unsigned long long pb2 = (w2 > 0) ? (s_mask[w2 - 1] >> 63) : (unsigned long long)pred;
-              const long long wb = t0 + 64ll * w2;
-              const unsigned long long R2 = M2 & ~((M2 << 1) | pb2) & bit_range(a.scan_lo - wb, a.scan_hi - wb);
-              if (R2) rg = wb + (63 - __builtin_clzll(R2));
+        // -- C: this tile's hits, in stream order: the list word and, built by the whole wavefront from the LDS
+        //    window while it still holds the burst's samples, the burst record (wave-uniform loop: a tile rarely has
+        //    more than one or two hits)
+        for (int m = 0; m < nm; ++m) {
+          const int slot2 = nrec + m;
+          if (slot2 >= a.rec_cap) break;                     // overflow: reported through the count, call is re-run
+          const unsigned e = (unsigned)adsb_uniform((int)s_rise[m]);
+          const int v = (int)(e & 0x7FFu);
+          if (e & kHitLongPulse) {
+            if (lane == 0) {
+              const long long rg = t0 + v;
+              my_cands[slot2] = cand_make(rg, kPending | kNoMatch);
+              const int li = atomicAdd(a.long_count, 1);
+              if (li < a.long_cap) { LongRise le; le.rise = rg; le.blk = (int)unit; le.slot = slot2; a.longlist[li] = le; }
             }
-            my_cands[slot] = cand_make(rg, kPending | kNoMatch);
-            const int li = atomicAdd(a.long_count, 1);
-            if (li < a.long_cap) { LongRise le; le.rise = rg; le.blk = (int)unit; le.slot = slot; a.longlist[li] = le; }
+          } else {
+            const bool lh = (e & kHitLongHint) != 0;
+            if (lane == 0) my_cands[slot2] = cand_make(t0 + (long long)v, lh ? kLongHint : 0u);
+            burst_from_window<MODE>(WinArgs{a.data, a.n, a.in0_base, a.dem_hi, a.origin, a.scale, a.sps}, s_x, t0, v,
+                                    lh ? kRecLongHint : 0u, my_recs + slot2, lane);
           }
-        } else {
-          const int p = (int)(e & 0x7FFFu);
-          const bool lh = (e & 0x10000u) != 0;
-          if (lane == 0) my_cands[slot] = cand_make(t0 + (long long)p, lh ? kLongHint : 0u);
-          burst_from_window<MODE>(WinArgs{a.data, a.n, a.in0_base, a.dem_hi, a.origin, a.scale, a.sps}, s_x, t0, p,
-                                  lh ? kRecLongHint : 0u, my_recs + slot, lane, pc.m1, pc.m2);
         }
+        nrec += nm;
       }
-      nrec += nm;
     }
 
-    // what the next tile inherits: back + forward halo (floats; mask words of the forward halo) and the last threshold bit
-    // (sources [kWTile-kBack, kWWin) and destinations [-kBack, kFwd) are disjoint: two short batches keep the
-    // register footprint of this step at four values)
-    const unsigned long long keepm = (lane < kHeadWords) ? s_mask[kWOwn + lane] : 0ull;
-    const int keepp = adsb_uniform((int)(s_mask[kWOwn - 1] >> 63));
+    // what the next tile inherits: back + forward halo (floats), the mask units of the forward halo and the last
+    // threshold bit (sources and destinations are disjoint; all reads are issued before the writes)
     {
-      float keep[kFwd / 64];
-#pragma unroll
-      for (int j = 0; j < kFwd / 64; ++j) keep[j] = s_x[kWTile + lane + 64 * j];
+      const float4 keep = *reinterpret_cast<const float4*>(s_x + kWTile + 4 * lane);
+      const float2 keepb = *reinterpret_cast<const float2*>(s_x + kWTile - kBack + 2 * lane);
+      const unsigned short keepm = s_m16[kTileUnits + (lane & (kHeadUnits - 1))];
       adsb_wave_sync();
-#pragma unroll
-      for (int j = 0; j < kFwd / 64; ++j) s_x[lane + 64 * j] = keep[j];
-      if (lane < kHeadWords) s_mask[lane] = keepm;
-    }
-    {
-      float keepb[kBack / 64];
-#pragma unroll
-      for (int j = 0; j < kBack / 64; ++j) keepb[j] = s_x[kWTile - kBack + lane + 64 * j];
-#pragma unroll
-      for (int j = 0; j < kBack / 64; ++j) s_x[lane + 64 * j - kBack] = keepb[j];
+      *reinterpret_cast<float4*>(s_x + 4 * lane) = keep;
+      *reinterpret_cast<float2*>(s_x - kBack + 2 * lane) = keepb;
+      s_m16[lane & (kHeadUnits - 1)] = keepm;
     }
     pred = keepp;
-    // (the next iteration's commit writes s_x[kFwd..] and mask words >= 4; its wave_sync orders all of it)
+    prev_active = active;
+    // (the next iteration's commit writes s_x[kFwd..] and mask units >= kHeadUnits; its wave_sync orders all of it)
   }
+  // largest paired pulse centre of the unit: once per unit
+#pragma unroll
+  for (int d2 = 32; d2 >= 1; d2 >>= 1) lp = imax(lp, __shfl_xor(lp, d2));
   if (lane == 0) {
     a.blk_count[unit] = nrec;
-    a.blk_lastp[unit] = lastp_g;
+    a.blk_lastp[unit] = lp >= 0 ? c0 + lp : kNoIndex;
     a.blk_flags[unit] = uflags;
   }
 }
@@ -996,7 +972,7 @@ __device__ __forceinline__ void longrun_body(int bid, int nb, const DetectArgs& 
         if (lane == 0) *out = match ? cand_make(p, hint) : cand_make(p, kNoMatch);
         if (match) {                                           // the centre's burst record, samples from global memory
           const BurstFetch<MODE> bf = burst_issue<MODE>(a, cand_make(p, hint), lane);
-          burst_finish<MODE>(a, bf, a.recs + (long long)le.blk * a.rec_cap + le.slot, lane, parity_consts(lane));
+          burst_finish<MODE>(a, bf, a.recs + (long long)le.blk * a.rec_cap + le.slot, lane);
         }
       } else if (lane == 0) {
         *out = cand_make(le.rise, kNoMatch);
@@ -1253,7 +1229,9 @@ __device__ __forceinline__ void compact_body(int bid, int nb, const unsigned lon
     if (seg == 0 && threadIdx.x == 0) sum->n_kept = total;
     if (k && off < out_cap) {
       Rec r = sorted_recs[i];
-      r.w[3] |= (unsigned long long)(cand_flags(c) & (kKept | kHead)) << 48;
+      unsigned fl = cand_flags(c) & (kKept | kHead);
+      if ((unsigned)(r.w[3] >> 48) & kDemod) fl |= parity_flags_of(r.w[2], r.w[3]);
+      r.w[3] |= (unsigned long long)fl << 48;
       out[off] = r;
       if (off == total - 1) sum->last_kept_p = cand_p(c);
     }

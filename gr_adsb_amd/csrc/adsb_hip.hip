@@ -4,8 +4,7 @@
 //   -> k_scan -> k_gather -> k_resolve -> k_count -> k_compact -> k_publish          (sparse lists only)
 // There is deliberately no CPU implementation of the path in this library.
 //
-// Tuning knobs exist only in side copies built with -DADSB_TUNING (tools/kbench.py); the shipped library reads no
-// environment variable.
+// The library reads no environment variable.
 #include <hip/hip_runtime.h>
 
 #include <cerrno>
@@ -30,18 +29,63 @@ __device__ __forceinline__ int adsb_opaque(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
-// streamed single-use data: non-temporal load (ADSB_NT_LOADS=0 in a tuning build restores the default cache policy)
-#ifndef ADSB_NT_LOADS
-#define ADSB_NT_LOADS 1
-#endif
+// streamed single-use data: non-temporal load (every sample is fetched exactly once)
 template <class Q>
 __device__ __forceinline__ Q adsb_ld_stream(const char* p) {
-#if ADSB_NT_LOADS
   using V = float __attribute__((ext_vector_type(sizeof(Q) / 4)));
   return __builtin_bit_cast(Q, __builtin_nontemporal_load(reinterpret_cast<const V*>(p)));
-#else
-  return *reinterpret_cast<const Q*>(p);
-#endif
+}
+// acc = 16*acc + the four threshold bits (x >= thr, NaN -> 0) of a, b, c, d (a highest): four compares into four
+// scalar pairs, then a chain of add-with-carry (acc = 2*acc + bit).  Batched by four because gfx950 wants two wait
+// states between a vector instruction that writes a scalar pair and a vector instruction that reads it: the three
+// other compares are that distance, no s_nop is spent.
+__device__ __forceinline__ unsigned adsb_above4(unsigned acc, float a, float b, float c, float d, float thr) {
+  unsigned long long ca, cb, cc, cd;
+  asm("v_cmp_le_f32 %1, %6, %7\n\t"
+      "v_cmp_le_f32 %2, %6, %8\n\t"
+      "v_cmp_le_f32 %3, %6, %9\n\t"
+      "v_cmp_le_f32 %4, %6, %10\n\t"
+      "v_addc_co_u32 %0, vcc, %5, %5, %1\n\t"
+      "v_addc_co_u32 %0, vcc, %0, %0, %2\n\t"
+      "v_addc_co_u32 %0, vcc, %0, %0, %3\n\t"
+      "v_addc_co_u32 %0, vcc, %0, %0, %4"
+      : "=&v"(acc), "=&s"(ca), "=&s"(cb), "=&s"(cc), "=&s"(cd)
+      : "v"(acc), "s"(thr), "v"(a), "v"(b), "v"(c), "v"(d)
+      : "vcc");
+  return acc;
+}
+// maximum of three floats with the hardware's own NaN rule (a quiet NaN operand is skipped); as an asm statement so that
+// no canonicalising instruction is spent on operands that come straight from memory
+__device__ __forceinline__ float adsb_fmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// the value of the lane below (lane 0: `fill`): DPP wave_shr:1
+__device__ __forceinline__ unsigned adsb_lane_up1(unsigned v, unsigned fill) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
+}
+// inclusive prefix sum over the 64 lanes: four row_shr steps inside each row of 16, then row_bcast:15 / row_bcast:31
+__device__ __forceinline__ unsigned adsb_wave_incl_scan(unsigned x) {
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
+  return x;
+}
+// minimum over the 64 lanes (wave-uniform result), same DPP ladder
+__device__ __forceinline__ unsigned adsb_wave_min_u32(unsigned v) {
+#define ADSB_MIN_STEP(ctrl, rows)                                                                  \
+  {                                                                                                \
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, ctrl, rows, 0xF, false);  \
+    v = o < v ? o : v;                                                                             \
+  }
+  ADSB_MIN_STEP(0x111, 0xF) ADSB_MIN_STEP(0x112, 0xF) ADSB_MIN_STEP(0x114, 0xF) ADSB_MIN_STEP(0x118, 0xF)
+  ADSB_MIN_STEP(0x142, 0xA) ADSB_MIN_STEP(0x143, 0xC)
+#undef ADSB_MIN_STEP
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 // workgroup-local (LDS) address space qualifier for pointers that crossed a function call as generic pointers
 #define ADSB_LDS __attribute__((address_space(3)))
@@ -116,6 +160,11 @@ struct adsb_ctx {
   bool own_stream = false;
   int n_cu = 256;
   int bpc[ADSB_FMT_COUNT] = {4, 4, 4, 4, 4};  // resident k_detect workgroups per CU (occupancy query), per input format
+  // Unused dynamic LDS per k_detect workgroup = how many workgroups share a CU.  complex64 (VGPR-limited) runs five per
+  // CU; the narrower formats would fit six, but measured FOUR per CU fastest (int16: 1043 vs 919 Gsamples/s with six,
+  // 930 with three; MI355X, tools/r3_variants.sh): 6 KB of padding lifts a workgroup over the 32 KB that five per CU allow
+  // and still leaves room for the tail kernels of the previous pass beside it.
+  unsigned det_dyn_lds[ADSB_FMT_COUNT] = {0, 6144, 6144, 6144, 6144};
   // integer IQ component -> float32 multiplier per format (adsb_set_format_scale); unused for the float formats
   float scale[ADSB_FMT_COUNT] = {1.0f, 1.0f, 1.0f / 32768.0f, 1.0f / 128.0f, 1.0f / 255.0f};
   FramerState st;       // framer.py:54,57
@@ -180,21 +229,24 @@ int ensure_pinned(adsb_ctx* c, void*& p, size_t& cap, size_t bytes) {
     default: F<4>(__VA_ARGS__); break;        \
   }
 
-#ifdef ADSB_TUNING
-// side copies for kernel tuning only (tools/kbench.py): integer knobs from the environment
-int tune_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
-#else
-constexpr int tune_int(const char*, int dflt) { return dflt; }
-#endif
-
+// k_detect is instantiated per input format and per samples-per-chip of the common rates (2, 4, 8, 20 Msps: the
+// preamble taps become immediate offsets); any other even rate runs the run-time-stride instance
 template <int MODE>
 void launch_detect(adsb_ctx* c, const DetectArgs& a, int grid) {
-  hipLaunchKernelGGL((k_detect<MODE>), dim3(grid), dim3(kThreads), 0, c->stream, a);
+  const unsigned dyn = c->det_dyn_lds[MODE];
+  switch (a.sps) {
+    case 2: hipLaunchKernelGGL((k_detect<MODE, 1>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
+    case 4: hipLaunchKernelGGL((k_detect<MODE, 2>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
+    case 8: hipLaunchKernelGGL((k_detect<MODE, 4>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
+    case 20: hipLaunchKernelGGL((k_detect<MODE, 10>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
+    default: hipLaunchKernelGGL((k_detect<MODE, 0>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
+  }
 }
 template <int MODE>
-int detect_occupancy() {
+int detect_occupancy(unsigned dyn) {
+  // (the instances of one format differ only in tap addressing: the same resources decide)
   int nb = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_detect<MODE>, kThreads, 0);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_detect<MODE, 0>, kThreads, dyn);
   if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
   return nb;
 }
@@ -288,12 +340,14 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   const int tile = kWTile;
   long long ntiles = (s.span + tile - 1) / tile;
   if (ntiles < 1) ntiles = 1;
-  const int bpc = tune_int("ADSB_TUNE_BPC", c->bpc[pl.mode]);
-  const long long umax = ((long long)c->n_cu * bpc - tune_int("ADSB_TUNE_GRID_SLACK", 0)) * upb;
+  const int bpc = c->bpc[pl.mode];
+  const long long umax = (long long)c->n_cu * bpc * upb;
   long long units = ntiles < umax ? ntiles : umax;
   const long long tiles_per = (ntiles + units - 1) / units;
   units = (ntiles + tiles_per - 1) / tiles_per;
   const long long chunk = tiles_per * tile;
+  // k_detect keeps pulse centres relative to the start of a unit's chunk in 32 bits
+  if (chunk >= (1ll << 30)) return fail(c, -EINVAL, "input too long for one call on this device (chunk per wavefront >= 2^30 samples)");
   const int grid = (int)((units + upb - 1) / upb);
   const int nlists = grid * upb;                           // units past `units` own nothing and report empty lists
   long long rc = (chunk / 256 + 64) << c->rec_cap_shift;
@@ -308,7 +362,7 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   // A pass that can deliver only a few records (the GNU Radio work() calls: a few thousand samples) writes them from
   // k_compact straight into the pinned, device-visible result buffer: no device->host copy and no second
   // synchronisation at adsb_wait (the 48-byte summary travels the same way); bulk passes keep the DMA copy.
-  const long long kDirectRecs = tune_int("ADSB_TUNE_DIRECT_RECS", 16384);
+  const long long kDirectRecs = 16384;
   s.direct = s.tot <= kDirectRecs;
   if (s.direct) { if ((r = ensure_pinned(c, s.h_out, s.h_out_cap, (size_t)s.tot * sizeof(Rec)))) return r; }
   else if ((r = ensure(c, s.d_out, (size_t)s.tot * sizeof(Rec)))) return r;
@@ -461,7 +515,7 @@ bool is_pinned_host(const void* p) {
 // Radio work() calls: a few thousand samples) are not copied to the device at all: the kernels read the page-locked
 // copy in place over PCIe, once -- one operation fewer in a call whose cost is operations, not bytes.
 int upload(adsb_ctx* c, const void* host, size_t bytes, void** d_out) {
-  const size_t kZeroCopyBytes = (size_t)tune_int("ADSB_TUNE_ZERO_COPY_BYTES", 256 << 10);
+  const size_t kZeroCopyBytes = (size_t)256 << 10;
   int rc;
   const void* src = host;
   const bool pinned = is_pinned_host(host);
@@ -526,11 +580,11 @@ int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
   {
     int nb;
-    if ((nb = detect_occupancy<0>()) > 0) c->bpc[0] = nb;
-    if ((nb = detect_occupancy<1>()) > 0) c->bpc[1] = nb;
-    if ((nb = detect_occupancy<2>()) > 0) c->bpc[2] = nb;
-    if ((nb = detect_occupancy<3>()) > 0) c->bpc[3] = nb;
-    if ((nb = detect_occupancy<4>()) > 0) c->bpc[4] = nb;
+    if ((nb = detect_occupancy<0>(c->det_dyn_lds[0])) > 0) c->bpc[0] = nb;
+    if ((nb = detect_occupancy<1>(c->det_dyn_lds[1])) > 0) c->bpc[1] = nb;
+    if ((nb = detect_occupancy<2>(c->det_dyn_lds[2])) > 0) c->bpc[2] = nb;
+    if ((nb = detect_occupancy<3>(c->det_dyn_lds[3])) > 0) c->bpc[3] = nb;
+    if ((nb = detect_occupancy<4>(c->det_dyn_lds[4])) > 0) c->bpc[4] = nb;
   }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return -EIO; }
   c->own_stream = true;

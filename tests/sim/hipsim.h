@@ -198,6 +198,31 @@ inline int adsb_opaque(int v) { return v; }
 #define ADSB_LDS
 template <class Q> inline Q adsb_ld_stream(const char* p) { Q q; memcpy(&q, p, sizeof(Q)); return q; }
 inline int adsb_readlane(int v, int lane) { return hipsim_shfl_idx(v, lane); }
+inline unsigned adsb_above4(unsigned acc, float a, float b, float c, float d, float thr) {
+  return (acc << 4) | ((a >= thr) ? 8u : 0u) | ((b >= thr) ? 4u : 0u) | ((c >= thr) ? 2u : 0u) | ((d >= thr) ? 1u : 0u);
+}
+inline float adsb_fmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+inline unsigned adsb_lane_up1(unsigned v, unsigned fill) {
+  const int lane = hipsim::cur_block()->cur & 63;
+  const unsigned r = hipsim_shfl_idx(v, lane ? lane - 1 : 0);
+  return lane ? r : fill;
+}
+inline unsigned adsb_wave_incl_scan(unsigned x) {
+  const int lane = hipsim::cur_block()->cur & 63;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned t = hipsim_shfl_idx(x, lane >= d ? lane - d : lane);
+    if (lane >= d) x += t;
+  }
+  return x;
+}
+inline unsigned adsb_wave_min_u32(unsigned v) {
+  const int lane = hipsim::cur_block()->cur & 63;
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned o = hipsim_shfl_idx(v, lane ^ d);
+    if (o < v) v = o;
+  }
+  return v;
+}
 inline unsigned long long adsb_bitrep32(unsigned x) {
   unsigned long long r = 0;
   for (int i = 0; i < 32; ++i) if ((x >> i) & 1u) r |= 3ull << (2 * i);

@@ -78,7 +78,23 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   a.blk_flags = blk_flags.data(); a.longlist = longlist.data(); a.long_count = &long_count;
   a.long_lastp = &long_lastp;
 
-  SIM_BY_MODE(mode, k_detect, grid, kThreads, a);
+  // the instance the library would launch (per format and samples per chip), like adsb_hip.hip: launch_detect()
+#define SIM_DETECT(MODE)                                                                   \
+  switch (sps) {                                                                           \
+    case 2: hipsim::launch(k_detect<MODE, 1>, grid, kThreads, a); break;                   \
+    case 4: hipsim::launch(k_detect<MODE, 2>, grid, kThreads, a); break;                   \
+    case 8: hipsim::launch(k_detect<MODE, 4>, grid, kThreads, a); break;                   \
+    case 20: hipsim::launch(k_detect<MODE, 10>, grid, kThreads, a); break;                 \
+    default: hipsim::launch(k_detect<MODE, 0>, grid, kThreads, a); break;                  \
+  }
+  switch (mode) {
+    case 0: SIM_DETECT(0) break;
+    case 1: SIM_DETECT(1) break;
+    case 2: SIM_DETECT(2) break;
+    case 3: SIM_DETECT(3) break;
+    default: SIM_DETECT(4) break;
+  }
+#undef SIM_DETECT
   // same choice as adsb_hip.hip: enqueue_tail(): small passes take the one-workgroup tail (g_tail_mode: 0 = as the
   // library decides, 1 = always the kernel chain, 2 = always the fused tail)
   const bool fused = g_tail_mode == 2 || (g_tail_mode == 0 && tot <= 16384);

@@ -345,9 +345,9 @@ __device__ __forceinline__ BurstFetch<MODE> burst_issue(const DetectArgs& a, uns
 // for l < 48, bit-pair 64+l (y1, y0) (demod.py:87-92); peak = in0[pulse_idx].  `dem` = the burst ends inside the demod
 // input (demod.py:82).  xflags: record flags already known (kRecLongHint; the tail adds kKept / kHead).  Lane 0
 // stores the 32-byte record.
-__device__ __forceinline__ void burst_reduce(long long offset, int nwin, bool val0, bool val1, float peak, float v0,
-                                             float v1, bool dem, float x1, float x0, float y1, float y0, unsigned xflags,
-                                             Rec* out, int lane) {
+// np.median of the noise window held by a wavefront (framer.py:156-159): lane l has window samples l and l + 64 (v0, v1;
+// valid iff val0, val1; nwin = window length).  Wave-uniform result.
+__device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, float v0, float v1) {
   const unsigned long long nanm = __ballot((val0 && v0 != v0) || (val1 && v1 != v1));
   const unsigned k0 = val0 ? f32_key(v0) : 0xFFFFFFFFu;      // lanes outside the window sort last
   const unsigned k1 = val1 ? f32_key(v1) : 0xFFFFFFFFu;
@@ -397,20 +397,34 @@ __device__ __forceinline__ void burst_reduce(long long offset, int nwin, bool va
     }
     med = __fmul_rn(__fadd_rn(key_f32(A), key_f32(B)), 0.5f);          // f32(a+b)/2
   }
+  return med;
+}
+
+// the two halves of a 32-byte burst record, stored by lane 0: offset + (peak, median), and 112 bits + flags
+__device__ __forceinline__ void rec_store_head(Rec* out, long long offset, float peak, float med, int lane) {
+  if (lane == 0) {
+    out->w[0] = (unsigned long long)offset;
+    out->w[1] = (unsigned long long)__builtin_bit_cast(unsigned, peak) |
+                ((unsigned long long)__builtin_bit_cast(unsigned, med) << 32);
+  }
+}
+// ma / mb = ballots of message bits 0..63 / 64..111; flags = kDemod | kRecLongHint (the tail adds kKept / kHead and the
+// parity pre-filter bits)
+__device__ __forceinline__ void rec_store_bits(Rec* out, unsigned long long ma, unsigned long long mb, unsigned flags, int lane) {
+  if (lane == 0) {
+    out->w[2] = __builtin_bswap64(__brevll(ma));
+    out->w[3] = (__builtin_bswap64(__brevll(mb)) & 0xFFFFFFFFFFFFull) | ((unsigned long long)flags << 48);
+  }
+}
+
+__device__ __forceinline__ void burst_reduce(long long offset, int nwin, bool val0, bool val1, float peak, float v0,
+                                             float v1, bool dem, float x1, float x0, float y1, float y0, unsigned xflags,
+                                             Rec* out, int lane) {
+  const float med = noise_median(nwin, val0, val1, v0, v1);
   const bool bitA = dem && x1 > x0, bitB = dem && lane < 48 && y1 > y0;                     // demod.py:95
   const unsigned long long ma = __ballot(bitA), mb = __ballot(bitB);
-  if (lane == 0) {
-    const unsigned long long ra = __builtin_bswap64(__brevll(ma));
-    const unsigned long long rb = __builtin_bswap64(__brevll(mb)) & 0xFFFFFFFFFFFFull;
-    const unsigned flags = (dem ? kDemod : 0u) | xflags;    // the tail adds kKept / kHead and the parity pre-filter bits
-    Rec r;
-    r.w[0] = (unsigned long long)offset;
-    r.w[1] = (unsigned long long)__builtin_bit_cast(unsigned, peak) |
-             ((unsigned long long)__builtin_bit_cast(unsigned, med) << 32);
-    r.w[2] = ra;
-    r.w[3] = rb | ((unsigned long long)flags << 48);
-    *out = r;
-  }
+  rec_store_head(out, offset, peak, med, lane);
+  rec_store_bits(out, ma, mb, (dem ? kDemod : 0u) | xflags, lane);
 }
 
 // Mode S parity pre-filter of one finished record (one THREAD per record, in the tail: k_compact), from its packed
@@ -489,16 +503,37 @@ __device__ void burst_finish(const DetectArgs& a, const BurstFetch<MODE>& f, Rec
 // Record of a centre found by k_detect, built by the whole wavefront while the centre's tile is still in its LDS
 // window s_x[-kBack .. kWWin) (index j <-> sample t0 + j; samples outside the buffer are zeros there too): the noise
 // window always lies inside it, the bit samples do for all of a 2 Msps burst that starts in the tile and for the
-// beginning of longer ones -- samples past the window come from global memory (they are the next thing this
-// wavefront streams anyway, so that fetch is served by the caches a moment later).  p = centre relative to t0.
+// beginning of longer ones (4 Msps and up).  The bits of such a burst are sliced as their samples ARRIVE in the window:
+// the record gets its first half now, the burst goes on the wavefront's pending list (PendList, in LDS) with the bits it
+// already has, and pend_step() takes the rest from the next tile(s) -- every sample still comes from LDS, nothing is
+// gathered from global memory.  (Only when the list is full, or at the very end of the wavefront's chunk, the missing
+// samples are read from global memory instead: pend_flush / the smp path below.)
 // Inlined into k_detect's hit loop: a real call would cost the callee's entry wait for ALL outstanding memory
 // operations, i.e. for the prefetch of the next tile, once per hit.
 struct WinArgs {
   const void* data; long long n, in0_base, dem_hi, origin; float scale; int sps;
 };
+constexpr int kMaxPend = 8;
+struct PendEntry { int slot; int p; unsigned flags; int pad_; unsigned long long ma, mb; };    // p = centre relative to the CURRENT t0
+struct PendList { PendEntry e[kMaxPend]; };
+
+// Bit pair k of a burst centred at p: samples j1 = p + 8*sps + k*sps and j1 + half (demod.py:75-91).  A pair is taken by
+// the first window that holds both samples: pairs with j1 + half in [lo, kWWin) -- lo = 0 when the burst is met, kFwd
+// (= kWWin - kWTile) on every later tile.  Returns the ballots of the bits taken now (bits 0..63 / 64..111).
+__device__ __forceinline__ void slice_window(const float* s_x, int p, int sps, int half, int lo, int lane,
+                                             unsigned long long* ma, unsigned long long* mb) {
+  const int ja = p + 8 * sps + lane * sps, jb = ja + 64 * sps;
+  const bool ta = ja + half >= lo && ja + half < kWWin, tb = lane < 48 && jb + half >= lo && jb + half < kWWin;
+  float x1 = 0.0f, x0 = 0.0f, y1 = 0.0f, y0 = 0.0f;
+  if (ta) { x1 = s_x[ja]; x0 = s_x[ja + half]; }
+  if (tb) { y1 = s_x[jb]; y0 = s_x[jb + half]; }
+  *ma = __ballot(ta && x1 > x0);                             // demod.py:95
+  *mb = __ballot(tb && y1 > y0);
+}
+
 template <int MODE>
 __device__ __forceinline__ void burst_from_window(WinArgs a, const float* s_x, long long t0, int p, unsigned xflags,
-                                                  Rec* out, int lane) {
+                                                  Rec* out, int slot, int lane, PendList* pend, int* n_pend) {
   const int sps = a.sps, half = sps >> 1;
   const long long P = t0 + p;
   long long wlo = P - kNoise;                                // framer.py:156: in0[max(0, pulse_idx-100) : pulse_idx]
@@ -510,20 +545,75 @@ __device__ __forceinline__ void burst_from_window(WinArgs a, const float* s_x, l
   const float v1 = val1 ? s_x[wl + lane + 64] : 0.0f;
   const float peak = s_x[p];
   const bool dem = P + 119ll * sps + half < a.dem_hi;        // demod.py:76,82 (sps even)
-  float x1 = 0.0f, x0 = 0.0f, y1 = 0.0f, y0 = 0.0f;
+  const float med = noise_median(nwin, val0, val1, v0, v1);
+  rec_store_head(out, a.origin + P, peak, med, lane);
+  const unsigned flags = (dem ? kDemod : 0u) | xflags;
+  unsigned long long ma = 0ull, mb = 0ull;
   if (dem) {                                                 // wave-uniform
-    const int j0 = p + 8 * sps + lane * sps;                 // demod.py:75,87
     if (p + 119 * sps + half < kWWin) {
-      // wave-uniform fast path (every 2 Msps burst that starts in the tile): all 224 bit samples lie in the LDS window
-      x1 = s_x[j0]; x0 = s_x[j0 + half];                     // demod.py:91
-      if (lane < 48) { y1 = s_x[j0 + 64 * sps]; y0 = s_x[j0 + 64 * sps + half]; }
+      // every 2 Msps burst that starts in the tile: all 224 bit samples lie in the LDS window
+      slice_window(s_x, p, sps, half, 0, lane, &ma, &mb);
+    } else if (*n_pend < kMaxPend) {
+      slice_window(s_x, p, sps, half, 0, lane, &ma, &mb);    // what is here already; the rest when it arrives
+      if (lane == 0) {
+        PendEntry e;
+        e.slot = slot; e.p = p; e.flags = flags; e.pad_ = 0; e.ma = ma; e.mb = mb;
+        pend->e[*n_pend] = e;
+      }
+      *n_pend += 1;
+      return;
     } else {
+      const int j0 = p + 8 * sps + lane * sps;               // demod.py:75,87
       auto smp = [&](int j) -> float { return (j < kWWin) ? s_x[j] : xg<MODE>(a.data, a.n, t0 + j, a.scale); };
-      x1 = smp(j0); x0 = smp(j0 + half);
+      const float x1 = smp(j0), x0 = smp(j0 + half);
+      float y1 = 0.0f, y0 = 0.0f;
       if (lane < 48) { y1 = smp(j0 + 64 * sps); y0 = smp(j0 + 64 * sps + half); }
+      ma = __ballot(x1 > x0);
+      mb = __ballot(lane < 48 && y1 > y0);
     }
   }
-  burst_reduce(a.origin + P, nwin, val0, val1, peak, v0, v1, dem, x1, x0, y1, y0, xflags, out, lane);
+  rec_store_bits(out, ma, mb, flags, lane);
+}
+
+// Once per tile, after its body is in the window: every pending burst takes the bit pairs that have arrived; a burst
+// whose last pair is in is finished (second half of its record stored) and leaves the list.  t_next = false on the
+// tile the entries were made (nothing to do yet); the list is compacted in place, order kept.
+__device__ __forceinline__ void pend_step(PendList* pend, int* n_pend, const float* s_x, Rec* my_recs, int sps, int half, int lane) {
+  int keep = 0;
+  for (int i = 0; i < *n_pend; ++i) {                        // wave-uniform
+    PendEntry e = pend->e[i];
+    e.p -= kWTile;                                           // the window has moved on by one tile
+    unsigned long long ma, mb;
+    slice_window(s_x, e.p, sps, half, kFwd, lane, &ma, &mb);
+    e.ma |= ma; e.mb |= mb;
+    adsb_wave_sync();                                        // every lane has read entry i before lane 0 rewrites the list
+    if (e.p + 119 * sps + half < kWWin) {                    // the last pair (k = 111) has been taken
+      rec_store_bits(my_recs + e.slot, e.ma, e.mb, e.flags, lane);
+    } else {
+      if (lane == 0) pend->e[keep] = e;
+      ++keep;
+    }
+    adsb_wave_sync();
+  }
+  *n_pend = keep;
+}
+
+// End of the wavefront's chunk: what is still pending takes its missing samples from global memory.
+template <int MODE>
+__device__ __forceinline__ void pend_flush(const PendList* pend, int n_pend, WinArgs a, const float* s_x, long long t0,
+                                           Rec* my_recs, int lane) {
+  const int sps = a.sps, half = sps >> 1;
+  for (int i = 0; i < n_pend; ++i) {
+    const PendEntry e = pend->e[i];                          // p relative to t0 (the last tile's start)
+    const int ja = e.p + 8 * sps + lane * sps, jb = ja + 64 * sps;
+    auto smp = [&](int j) -> float { return (j < kWWin) ? s_x[j] : xg<MODE>(a.data, a.n, t0 + j, a.scale); };
+    const bool ta = ja + half >= kWWin, tb = lane < 48 && jb + half >= kWWin;     // pairs no window has held
+    float x1 = 0.0f, x0 = 0.0f, y1 = 0.0f, y0 = 0.0f;
+    if (ta) { x1 = smp(ja); x0 = smp(ja + half); }
+    if (tb) { y1 = smp(jb); y0 = smp(jb + half); }
+    const unsigned long long ma = e.ma | __ballot(ta && x1 > x0), mb = e.mb | __ballot(tb && y1 > y0);
+    rec_store_bits(my_recs + e.slot, ma, mb, e.flags, lane);
+  }
 }
 
 // ---- k_detect: the streaming kernel, one independent stream segment per WAVEFRONT -------------------
@@ -673,12 +763,15 @@ __global__ void __launch_bounds__(kThreads, kMinWaves) k_detect(DetectArgs a) {
   __shared__ __attribute__((aligned(16))) float s_xa[kWaves][kBack + kWWin];
   __shared__ __attribute__((aligned(16))) unsigned s_ma[kWaves][kMaskDwords];
   __shared__ __attribute__((aligned(4))) unsigned short s_risea[kWaves][kWTile / 2];
+  __shared__ PendList s_penda[kWaves];
 
   const int lane = threadIdx.x & 63, wave = adsb_uniform((int)(threadIdx.x >> 6));
   float* s_x = s_xa[wave] + kBack;                           // s_x[j] <-> sample t0 + j, j in [-kBack, kWWin)
   u32_alias* s_m32 = reinterpret_cast<u32_alias*>(s_ma[wave]);
   u16_alias* s_m16 = reinterpret_cast<u16_alias*>(s_ma[wave]);     // unit u <-> samples [16u, 16u + 16) of the window
   u16_alias* s_rise = reinterpret_cast<u16_alias*>(s_risea[wave]);
+  PendList* pend = &s_penda[wave];
+  int n_pend = 0;                                            // wave-uniform: bursts whose last bit samples have not arrived yet
   const long long unit = (long long)blockIdx.x * kWaves + wave;
   const long long c0 = unit * a.chunk;
   long long c1 = c0 + a.chunk;
@@ -776,6 +869,8 @@ __global__ void __launch_bounds__(kThreads, kMinWaves) k_detect(DetectArgs a) {
     if (active) bm = unit_mask(s_x + kFwd + kUnit * lane, thr);      // wave-uniform branch
     s_m16[kHeadUnits + lane] = (unsigned short)bm;
     adsb_wave_sync();
+    // -- P: bursts met in earlier tiles take the bit samples that have arrived with this body
+    if (n_pend > 0) pend_step(pend, &n_pend, s_x, my_recs, a.sps, half, lane);
 
     // -- B: rises among the tile's own samples (units 0 .. 63); a tile can hold one only if this or the previous body
     //       had a sample above the threshold (or the sample in front of the tile was)
@@ -892,13 +987,18 @@ __global__ void __launch_bounds__(kThreads, kMinWaves) k_detect(DetectArgs a) {
             const bool lh = (e & kHitLongHint) != 0;
             if (lane == 0) my_cands[slot2] = cand_make(t0 + (long long)v, lh ? kLongHint : 0u);
             burst_from_window<MODE>(WinArgs{a.data, a.n, a.in0_base, a.dem_hi, a.origin, a.scale, a.sps}, s_x, t0, v,
-                                    lh ? kRecLongHint : 0u, my_recs + slot2, lane);
+                                    lh ? kRecLongHint : 0u, my_recs + slot2, slot2, lane, pend, &n_pend);
           }
         }
         nrec += nm;
       }
     }
 
+    if (n_pend > 0 && it + 1 == ntile) {                     // end of this wavefront's chunk
+      adsb_wave_sync();
+      pend_flush<MODE>(pend, n_pend, WinArgs{a.data, a.n, a.in0_base, a.dem_hi, a.origin, a.scale, a.sps}, s_x, t0, my_recs, lane);
+      n_pend = 0;
+    }
     // what the next tile inherits: back + forward halo (floats), the mask units of the forward halo and the last
     // threshold bit (sources and destinations are disjoint; all reads are issued before the writes)
     {

@@ -35,7 +35,7 @@ BURST_LONG_HINT = 0x2000 # records of a long-aware context: this burst holds the
 MAX_IN_FLIGHT = 3
 
 EXPORTS = [
-    "adsb_abi_version", "adsb_create", "adsb_destroy", "adsb_set_threshold", "adsb_set_stream", "adsb_reset",
+    "adsb_abi_version", "adsb_create", "adsb_destroy", "adsb_set_threshold", "adsb_set_stream", "adsb_wait_for_event", "adsb_reset", "adsb_framer_state",
     "adsb_process_iq", "adsb_process_mag2", "adsb_process_iq_device", "adsb_process_mag2_device", "adsb_last_result",
     "adsb_submit_iq_device", "adsb_submit_mag2_device", "adsb_submit_iq16_device", "adsb_submit_shard_device", "adsb_wait",
     "adsb_set_iq16_scale", "adsb_process_iq16", "adsb_process_iq16_device",
@@ -90,6 +90,8 @@ def load():
     lib.adsb_set_threshold.argtypes = [vp, f32]
     lib.adsb_set_stream.argtypes = [vp, vp]
     lib.adsb_reset.argtypes = [vp]
+    lib.adsb_wait_for_event.argtypes = [vp, vp]
+    lib.adsb_framer_state.argtypes = [vp, c.POINTER(c.c_float), c.POINTER(c.c_int64)]
     lib.adsb_set_iq16_scale.argtypes = [vp, f32]
     lib.adsb_submit_iq16_device.argtypes = [vp, vp, i64, i64, c.POINTER(i32)]
     for name in ("adsb_process_iq", "adsb_process_mag2", "adsb_process_iq_device", "adsb_process_mag2_device",
@@ -287,8 +289,22 @@ class Context:
 
     def wait(self, ticket, fetch=True, copy=True):
         n_out = ctypes.c_int32(0)
-        self._chk(self.lib.adsb_wait(self._h, int(ticket), None, 0, ctypes.byref(n_out)))
+        try:
+            self._chk(self.lib.adsb_wait(self._h, int(ticket), None, 0, ctypes.byref(n_out)))
+        finally:
+            # the host buffer of a host-fed submission was only kept alive for the upload: let go of it now, also on error
+            getattr(self, "_host_keepalive", {}).pop(int(ticket), None)
         return self.last_result(copy=copy) if fetch else n_out.value
+
+    def wait_for_event(self, hip_event):
+        """Everything submitted next runs after this hipEvent_t (raw handle) has completed: device-side ordering."""
+        self._chk(self.lib.adsb_wait_for_event(self._h, ctypes.c_void_p(int(hip_event))))
+
+    def framer_state(self):
+        """(prev_in0, prev_eob_idx): the reference framer's cross-call attributes (framer.py:54,57)."""
+        p, e = ctypes.c_float(0), ctypes.c_int64(0)
+        self._chk(self.lib.adsb_framer_state(self._h, ctypes.byref(p), ctypes.byref(e)))
+        return np.float32(p.value), int(e.value)
 
     def framer_work(self, in0, N, nitems_written):
         in0 = np.ascontiguousarray(in0, dtype=np.float32)

@@ -78,9 +78,15 @@ class framer(gr.sync_block):
     def set_threshold(self, threshold):
         self.threshold = threshold            # read once per work(), like the reference (framer.py:84)
 
+    # the reference keeps its cross-call state as public attributes of the block (framer.py:54,57); here it lives in the
+    # library's context (adsb_framer_work) and is read back on demand.  Not meaningful with improved=True.
     @property
     def prev_eob_idx(self):
-        return None
+        return None if self.improved else self._ctx.framer_state()[1]
+
+    @property
+    def prev_in0(self):
+        return None if self.improved else self._ctx.framer_state()[0]
 
     def _work_improved(self, in0, out0):
         """One overlapped shard of the unbounded input stream per call (the multi-GPU stitching machinery used in

@@ -403,14 +403,20 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
 // Wait for a queued call; handle the two rare outcomes that need a second pass (pulses longer than the
 // LDS window; per-workgroup list overflow); bring the records to pinned host memory.
 int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
-  HIPCHK(c, hipSetDevice(c->device));
+  // every error exit releases the slot: a failed call must not leave its ticket busy for good
+#define FINCHK(call)                                                           \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) { s.busy = false; return fail(c, -EIO, #call, e_); } \
+  } while (0)
+  FINCHK(hipSetDevice(c->device));
   const bool timing = (c->flags & ADSB_FLAG_TIMING) != 0;
   for (int attempt = 0; attempt < 16; ++attempt) {
-    HIPCHK(c, hipEventSynchronize(s.done));
-    HIPCHK(c, hipGetLastError());
+    FINCHK(hipEventSynchronize(s.done));
+    FINCHK(hipGetLastError());
     if (timing) {
       float ms = 0;
-      HIPCHK(c, hipEventElapsedTime(&ms, s.ev0, s.ev1));
+      FINCHK(hipEventElapsedTime(&ms, s.ev0, s.ev1));
       c->stats.detect_launches++;
       c->stats.detect_ms += ms;
       // idle time on the compute stream between the previous pass's k_detect and this one (pipelined use)
@@ -445,21 +451,21 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
     const Rec* recs_dev = (const Rec*)(s.direct ? s.h_out : s.d_out.p);
     if (nres > 0 && (!s.direct || (c->flags & ADSB_FLAG_CONFIDENCE))) {
       if (!s.direct)
-        HIPCHK(c, hipMemcpyAsync(s.h_out, s.d_out.p, (size_t)nres * sizeof(Rec), hipMemcpyDeviceToHost, c->copy_stream));
+        FINCHK(hipMemcpyAsync(s.h_out, s.d_out.p, (size_t)nres * sizeof(Rec), hipMemcpyDeviceToHost, c->copy_stream));
       if (c->flags & ADSB_FLAG_CONFIDENCE) {
         // opt-in (demod.py:97-101): bit1/bit0 ratios of the delivered records, computed now that their number is
         // known -- one more small kernel and copy on the copy stream, paid only by callers who ask for it
         const size_t rb = (size_t)nres * 112 * sizeof(float);
         if ((r = ensure(c, s.d_ratio, rb)) || (r = ensure_pinned(c, s.h_ratio, s.h_ratio_cap, rb))) { s.busy = false; return r; }
-        HIPCHK(c, hipMemsetAsync(s.d_ratio.p, 0, rb, c->copy_stream));
+        FINCHK(hipMemsetAsync(s.d_ratio.p, 0, rb, c->copy_stream));
         int cg = (nres + kWaves - 1) / kWaves;
         if (cg > c->n_cu * 8) cg = c->n_cu * 8;
         ADSB_BY_MODE(s.plan.mode, launch_confidence, c->copy_stream, cg, s.args, recs_dev,
                      (const Summary*)&((Misc*)s.d_misc.p)->sum, nres, (float*)s.d_ratio.p);
-        HIPCHK(c, hipMemcpyAsync(s.h_ratio, s.d_ratio.p, rb, hipMemcpyDeviceToHost, c->copy_stream));
+        FINCHK(hipMemcpyAsync(s.h_ratio, s.d_ratio.p, rb, hipMemcpyDeviceToHost, c->copy_stream));
       }
-      HIPCHK(c, hipStreamSynchronize(c->copy_stream));
-      HIPCHK(c, hipGetLastError());
+      FINCHK(hipStreamSynchronize(c->copy_stream));
+      FINCHK(hipGetLastError());
     }
     s.nres = nres;
     *n_res = nres;
@@ -468,6 +474,7 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
   }
   s.busy = false;
   return fail(c, -EIO, "centre list capacity did not converge");
+#undef FINCHK
 }
 
 // Synchronous form used by every blocking entry point.
@@ -509,6 +516,15 @@ bool is_pinned_host(const void* p) {
   return at.type == hipMemoryTypeHost;
 }
 
+// The address under which the DEVICE sees a page-locked host buffer.  For hipHostMalloc'ed memory it equals the host
+// address on ROCm; for memory page-locked in place (adsb_host_register -> hipHostRegister) HIP only promises access
+// through the alias hipHostGetDevicePointer returns.  nullptr: not mapped -- the caller stages instead.
+const void* device_alias(const void* host) {
+  void* dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, const_cast<void*>(host), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return dev;
+}
+
 // Host buffer -> something the kernels can read, for the blocking entry points (the buffer only has to stay valid until
 // the call returns).  Large inputs are copied to the device: page-locked sources (adsb_host_alloc, hipHostMalloc, torch
 // pin_memory) go straight over PCIe, pageable ones through the context's pinned staging buffer.  Small inputs (the GNU
@@ -519,13 +535,16 @@ int upload(adsb_ctx* c, const void* host, size_t bytes, void** d_out) {
   int rc;
   const void* src = host;
   const bool pinned = is_pinned_host(host);
-  if (!pinned || (bytes <= kZeroCopyBytes && ((uintptr_t)host & 15u) != 0)) {
+  const bool small = bytes <= kZeroCopyBytes;
+  const void* alias = (pinned && small) ? device_alias(host) : nullptr;     // only the in-place path needs it
+  if (!pinned || (small && (!alias || ((uintptr_t)alias & 15u) != 0))) {
     if ((rc = ensure_pinned(c, c->h_stage, c->h_stage_cap, bytes))) return rc;
     memcpy(c->h_stage, host, bytes);
     src = c->h_stage;
+    alias = c->h_stage;                                   // hipHostMalloc'ed: one address on both sides
   }
-  if (bytes <= kZeroCopyBytes) {
-    *d_out = const_cast<void*>(src);
+  if (small) {
+    *d_out = const_cast<void*>(alias);
     return 0;
   }
   if ((rc = ensure(c, c->d_in, bytes + 64))) return rc;
@@ -654,9 +673,25 @@ int adsb_set_stream(adsb_ctx* c, void* hip_stream) {
   return 0;
 }
 
+int adsb_wait_for_event(adsb_ctx* c, void* hip_event) {
+  if (!c || !hip_event) return -EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  // whatever is submitted next (kernels on the compute stream, uploads on the upload stream) runs after the event
+  HIPCHK(c, hipStreamWaitEvent(c->stream, (hipEvent_t)hip_event, 0));
+  HIPCHK(c, hipStreamWaitEvent(c->h2d_stream, (hipEvent_t)hip_event, 0));
+  return 0;
+}
+
 int adsb_reset(adsb_ctx* c) {
   if (!c) return -EINVAL;
   c->st = FramerState();
+  return 0;
+}
+
+int adsb_framer_state(adsb_ctx* c, float* prev_in0, int64_t* prev_eob_idx) {
+  if (!c) return -EINVAL;
+  if (prev_in0) *prev_in0 = c->st.prev_in0;
+  if (prev_eob_idx) *prev_eob_idx = (int64_t)c->st.prev_eob;
   return 0;
 }
 
@@ -915,7 +950,11 @@ static int shard_post(adsb_ctx* c, Slot& s, const Summary& sum, int32_t* nres_io
       return fail(c, -EOVERFLOW, "burst runs past the shard's forward halo");
     }
     if (off - 100 < origin && origin > 0) return fail(c, -EOVERFLOW, "noise window runs past the shard's back halo");
-    if (w != i) r[w] = r[i];
+    if (w != i) {
+      r[w] = r[i];
+      // row t of adsb_last_confidence belongs to record t of the delivered list: rows move with their records
+      if ((c->flags & ADSB_FLAG_CONFIDENCE) && s.h_ratio) memcpy((float*)s.h_ratio + (size_t)w * 112, (float*)s.h_ratio + (size_t)i * 112, 112 * sizeof(float));
+    }
     ++w;
   }
   s.nres = w;

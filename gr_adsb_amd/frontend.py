@@ -29,13 +29,18 @@ def shard_plan(stream_len, n_shards, sps, max_run=256, align=4096):
     return plans
 
 
-def _after_torch(t):
-    """The context runs on its own HIP stream: whatever torch still has queued on ITS current stream for this tensor
-    (the kernels that produce it) must have finished before our kernels read it.  A no-op when that stream is idle.
+def _after_torch(ctx, t):
+    """The context runs on its own HIP streams: whatever torch still has queued on ITS current stream for this tensor
+    (the kernels that produce it) must have finished before our kernels read it.  A device-side dependency -- an event
+    recorded on torch's stream that the context's streams wait for (adsb_wait_for_event); the host does not block, so
+    a producer still running does not serialise the submit / wait pipeline.
     (adsb_set_stream / FrontEnd.use_torch_stream is the alternative: share torch's stream and skip this.)"""
     import torch
     assert t.is_cuda and t.is_contiguous()
-    torch.cuda.current_stream(t.device).synchronize()
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(t.device))
+    ctx.wait_for_event(ev.cuda_event)
+    ctx._torch_events = (getattr(ctx, "_torch_events", []) + [ev])[-8:]      # alive until the dependency has been queued
 
 
 class FrontEnd:
@@ -78,42 +83,42 @@ class FrontEnd:
     # -- torch tensors already in HBM ---------------------------------------------------------------
     def process_format_tensor(self, fmt, t, abs_offset=0, fetch=True):
         """t: contiguous CUDA tensor whose first dimension is the sample count ([n,2] for the IQ formats)."""
-        _after_torch(t)
+        _after_torch(self.ctx, t)
         return self.ctx.process_format_device(fmt, t.data_ptr(), t.shape[0], abs_offset, fetch=fetch)
 
     def submit_format_tensor(self, fmt, t, abs_offset=0):
-        _after_torch(t)
+        _after_torch(self.ctx, t)
         return self.ctx.submit_format_device(fmt, t.data_ptr(), t.shape[0], abs_offset)
 
     def process_iq_tensor(self, t, abs_offset=0, fetch=True):
         """t: float32 [n,2] (or complex64 [n]) CUDA tensor, contiguous."""
-        _after_torch(t)
+        _after_torch(self.ctx, t)
         n = t.shape[0]
         return self.ctx.process_iq_device(t.data_ptr(), n, abs_offset, fetch=fetch)
 
     def process_mag2_tensor(self, t, abs_offset=0, fetch=True):
-        _after_torch(t)
+        _after_torch(self.ctx, t)
         return self.ctx.process_mag2_device(t.data_ptr(), t.shape[0], abs_offset, fetch=fetch)
 
     def submit_iq16_tensor(self, t, abs_offset=0):
         """t: int16 [n,2] CUDA tensor (interleaved I,Q)."""
-        _after_torch(t)
+        _after_torch(self.ctx, t)
         return self.ctx.submit_iq16_device(t.data_ptr(), t.shape[0], abs_offset)
 
     def submit_iq_tensor(self, t, abs_offset=0):
         """Queue a canonical pass over t (up to _native.MAX_IN_FLIGHT in flight); returns a ticket for wait()."""
-        _after_torch(t)
+        _after_torch(self.ctx, t)
         return self.ctx.submit_iq_device(t.data_ptr(), t.shape[0], abs_offset)
 
     def submit_shard_tensor(self, t, origin, own_lo, own_hi, stream_len, fmt=0, head_cands=0):
-        _after_torch(t)
+        _after_torch(self.ctx, t)
         return self.ctx.submit_shard_device(fmt, t.data_ptr(), t.shape[0], origin, own_lo, own_hi, stream_len, head_cands)
 
     def wait(self, ticket, fetch=True, copy=True):
         return self.ctx.wait(ticket, fetch=fetch, copy=copy)
 
     def shard_tensor(self, t, origin, own_lo, own_hi, stream_len, fmt=0, head_cands=0):
-        _after_torch(t)
+        _after_torch(self.ctx, t)
         return self.ctx.shard_device(fmt, t.data_ptr(), t.shape[0], origin, own_lo, own_hi, stream_len, head_cands)
 
     def stitch(self, cand_lists):

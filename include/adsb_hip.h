@@ -125,8 +125,15 @@ int adsb_set_threshold(adsb_ctx* ctx, float threshold);
  * buffer first.  -EBUSY while submitted calls are pending.  A context is used from one thread at a time;
  * different contexts are independent. */
 int adsb_set_stream(adsb_ctx* ctx, void* hip_stream);
+/* Order everything submitted to this context AFTER a HIP event of the caller (hipEvent_t recorded on the stream that
+ * produces a device-resident input, e.g. a framework's current stream): a device-side dependency, the host does not
+ * wait.  The event may be destroyed once the next call on the context has returned. */
+int adsb_wait_for_event(adsb_ctx* ctx, void* hip_event);
 /* Forget the framer's cross-call state (prev_in0 = 0, prev_eob = -1; framer.py:54,57). */
 int adsb_reset(adsb_ctx* ctx);
+/* The framer's two words of cross-call state as the reference keeps them on the block (framer.py:54 `prev_in0`, :57
+ * `prev_eob_idx`, both public attributes there): what adsb_framer_work carries between calls.  Either pointer may be NULL. */
+int adsb_framer_state(adsb_ctx* ctx, float* prev_in0, int64_t* prev_eob_idx);
 
 /* Canonical whole-buffer mode: ONE framer.work() call over n samples of a fresh stream (history =
  * 8*sps-1 zeros) followed by ONE demod.work() call over the same n samples with all tags delivered.

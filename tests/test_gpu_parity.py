@@ -6,7 +6,8 @@ import warnings
 import numpy as np
 import pytest
 
-from helpers import SCHEDULES, Golden, assert_recs_equal, assert_recs_match_golden, golden_names, snr_bits, unpack
+from helpers import (SCHEDULES, Golden, assert_recs_equal, assert_recs_match_golden, golden_names, large_golden_names,
+                     pathological_names, schedules_of, snr_bits, unpack)
 
 pytestmark = pytest.mark.gpu
 
@@ -39,6 +40,71 @@ def test_canonical_host_iq_matches_reference_goldens(native, name):
     st = ctx.stats()
     assert st["calls"] == 2
     ctx.close()
+
+
+@pytest.mark.parametrize("name", large_golden_names())
+def test_large_reference_goldens_every_entry_point(native, torch_mod, name):
+    """tests/golden/L*.npz (round 3): 2^20 .. 3*2^20 samples per rate, >= 500 reference tags each (20 Msps included), stored as
+    int8 IQ -- so the reference's own outputs pin the cs8 entry point (the bytes as they are), the complex64 and the
+    |IQ|^2 entry points (the oracle's exact conversion of the same bytes), host, device-resident, submitted and host-fed."""
+    g = Golden(name)
+    assert len(g.get("single", "tag_offsets")) >= 490
+    ctx = native.Context(g.fs, g.thr)
+    ctx.set_format_scale(native.FMT_SC8, float(g.scale))
+    n = len(g.x)
+    assert_recs_match_golden(ctx.process_format(native.FMT_SC8, g.iq8), g)
+    assert_recs_match_golden(ctx.process_iq(g.iq), g)
+    assert_recs_match_golden(ctx.process_mag2(g.x), g)
+    t = torch_mod.from_numpy(g.iq8.copy()).to("cuda:0")
+    assert_recs_match_golden(ctx.process_format_device(native.FMT_SC8, t.data_ptr(), n), g)
+    assert_recs_match_golden(ctx.wait(ctx.submit_format_device(native.FMT_SC8, t.data_ptr(), n)), g)
+    assert_recs_match_golden(ctx.wait(ctx.submit_format_host(native.FMT_MAG2, g.x)), g)
+    ctx.close()
+
+
+def _drive_blocks_vs_golden(g, sched, improved=False):
+    from gr_adsb_amd import blocks, grshim
+    fr = blocks.framer(g.fs, g.thr)
+    dm = blocks.demod(g.fs)
+    dm.start_timestamp = 0.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tags, msgs = grshim.drive(fr, dm, g.x, None if sched == "single" else g.sched(sched))
+    assert np.array_equal(np.array([t.offset for t in tags], dtype=np.int64), g.get(sched, "tag_offsets"))
+    snr = np.array([t.value[1] for t in tags], dtype=np.float32)
+    assert np.array_equal(snr.view(np.uint32), g.get(sched, "tag_snr_bits"))
+    offs = np.array([int(round(m[0]["timestamp"] * g.fs)) for _, m in msgs], dtype=np.int64)
+    assert np.array_equal(offs, g.get(sched, "pdu_offsets"))
+    bits = np.array([m[1] for _, m in msgs], dtype=np.uint8).reshape(-1, 112)
+    assert np.array_equal(bits, g.pdu_bits(sched))
+    psnr = np.array([m[0]["snr"] for _, m in msgs], dtype=np.float32)
+    assert np.array_equal(psnr.view(np.uint32), g.get(sched, "pdu_snr_bits"))
+    # the framer's two words of cross-call state after the last call (framer.py:54,57)
+    assert fr.prev_eob_idx == int(g.get(sched, "final_prev_eob"))
+    assert np.float32(fr.prev_in0).view(np.uint32) == g.get(sched, "final_prev_in0_bits")
+
+
+@pytest.mark.parametrize("name", large_golden_names())
+@pytest.mark.parametrize("sched", ["fixed2048", "random"])
+def test_dropin_blocks_match_large_reference_goldens(native, name, sched):
+    """The drop-in blocks, work() call by work() call, against the reference under the deaf-state schedule (fixed 2048,
+    framer.py:177-179) and a random 1000-9000 schedule over megasample streams."""
+    _drive_blocks_vs_golden(Golden(name), sched)
+
+
+@pytest.mark.parametrize("name", pathological_names())
+def test_pathological_reference_goldens(native, name):
+    """tests/golden/P*.npz (round 3): NaN / inf, thresholds <= 0, plateaus over several tiles, streams that start / end
+    above the threshold, exact ties, tiny inputs -- the REFERENCE's outputs for them (not only the C oracle's), through the
+    canonical |IQ|^2 entry point and through the drop-in blocks under every stored schedule."""
+    g = Golden(name)
+    ctx = native.Context(g.fs, g.thr)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert_recs_match_golden(ctx.process_mag2(g.x), g)
+    ctx.close()
+    for sched in schedules_of(name):
+        _drive_blocks_vs_golden(g, sched)
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -788,6 +854,65 @@ def test_host_fed_pipeline_equals_blocking_calls(native):
         for _ in range(native.MAX_IN_FLIGHT + 1):
             ctx.submit_format_host(native.FMT_FC32, chunks[0])
     ctx.close()
+
+
+def test_registered_buffers_small_calls_read_in_place(native):
+    """Inputs of <= 256 KB are not copied to the device: the kernels read the page-locked buffer in place through its
+    DEVICE alias (hipHostGetDevicePointer).  For memory page-locked by registration (adsb_host_register) that alias is
+    the only address HIP promises -- every small-call entry point on registered buffers, aligned and not, against the
+    same calls on pageable copies (which go through the library's own staging buffer)."""
+    from gr_adsb_amd import blocks, grshim
+    from gr_adsb_amd import modulator as M
+    g = Golden("g2msps_df17")
+    ctx = native.Context(g.fs, g.thr)
+    n = 30000                                           # 120 KB of |IQ|^2, 240 KB of complex64: the in-place branch
+    x, iq = g.x[:n].copy(), g.iq[:n].copy()
+    want_x, want_iq = ctx.process_mag2(x), ctx.process_iq(iq)
+    assert len(want_x) > 10
+    with native.RegisteredArray(x) as rx, native.RegisteredArray(iq) as riq:
+        assert_recs_equal(ctx.process_mag2(rx.array), want_x, "registered |IQ|^2, in place")
+        assert_recs_equal(ctx.process_iq(riq.array), want_iq, "registered complex64, in place")
+        assert_recs_equal(ctx.process_mag2(rx.array[3:]), ctx.process_mag2(x[3:].copy()), "registered, 12-byte offset (staged)")
+        assert_recs_equal(ctx.process_mag2(rx.array[4:]), ctx.process_mag2(x[4:].copy()), "registered, 16-byte offset (in place)")
+        # the GNU Radio emulation entry points on a registered ring buffer: framer.work() / demod.work() chunk by chunk
+        H = 8 * g.sps
+        buf = np.concatenate([np.zeros(H - 1, np.float32), x])
+        with native.RegisteredArray(buf) as rb:
+            st = native.Context(g.fs, g.thr)
+            ref = native.Context(g.fs, g.thr)
+            pos = 0
+            for N in (4096, 4096, 8192, 2048, 11568):
+                a_ = st.framer_work(rb.array[pos:pos + N + H - 1], N, pos)
+                b_ = ref.framer_work(buf[pos:pos + N + H - 1].copy(), N, pos)
+                assert_recs_equal(a_, b_, "framer_work on a registered ring, pos %d" % pos)
+                pos += N
+            assert st.framer_state() == ref.framer_state()
+            tags = want_x["offset"][:40]
+            bits_a, ok_a, ra = st.demod_work(rx.array, 0, tags, want_ratio=True)
+            bits_b, ok_b, rb_ = ref.demod_work(x.copy(), 0, tags, want_ratio=True)
+            assert np.array_equal(bits_a, bits_b) and np.array_equal(ok_a, ok_b) and np.array_equal(ra.view(np.uint32), rb_.view(np.uint32))
+    ctx.close()
+
+
+def test_device_side_ordering_after_a_torch_producer(native, torch_mod):
+    """FrontEnd tensor entry points order the context's streams behind torch's current stream with an event
+    (adsb_wait_for_event), without blocking the host: a producer kernel queued on torch's stream right before the
+    submit must be seen complete by k_detect."""
+    from gr_adsb_amd.frontend import FrontEnd
+    from gr_adsb_amd import modulator as M
+    iq = M.synth_iq(1 << 22, 2e6, 3000, seed=77)
+    fe = FrontEnd(2e6, 0.01)
+    want = fe.process_iq(iq)
+    src = to_dev(torch_mod, iq)
+    for rep in range(5):
+        dst = torch_mod.zeros_like(src)
+        junk = torch_mod.randn(1 << 24, device="cuda:0")
+        for _ in range(8):                               # keep torch's stream busy in front of the producer
+            junk = junk * 1.0001 + 0.5
+        dst.copy_(src)                                   # the producer: queued, not finished, when submit is called
+        tk = fe.submit_iq_tensor(dst, 0)
+        assert_recs_equal(fe.wait(tk), want, "rep %d" % rep)
+    assert_recs_equal(fe.process_iq_tensor(src), want, "blocking entry point")
 
 
 @pytest.mark.parametrize("n", [6000, 6600])        # pulse inside k_detect's LDS window / longer than it (k_longrun)

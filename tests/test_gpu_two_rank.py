@@ -76,7 +76,7 @@ def _worker(rank, world, port, case, n, q):
 # n = 30000: shard 0's last kept preamble is 14850 again but shard 1 begins at 15050, beyond it: local fix-up suffices
 @pytest.mark.parametrize("case,n,world,fallback", [("synthetic", 1 << 18, 2, False), ("chain", 29800, 2, True),
                                                    ("chain", 30000, 2, False), ("chain", 1500, 3, True),
-                                                   ("synthetic", 70000, 4, False)])
+                                                   ("synthetic", 70000, 4, False), ("synthetic", 1 << 19, 8, False)])
 def test_ranks_on_gpu_equal_one_canonical_call(case, n, world, fallback):
     import torch.multiprocessing as mp
     from gr_adsb_amd import _native
@@ -99,6 +99,25 @@ def test_ranks_on_gpu_equal_one_canonical_call(case, n, world, fallback):
     assert np.array_equal(got["flags"] & 0x1FE1, want["flags"] & 0x1FE1)
     assert len(set(fallbacks)) == 1                                          # every rank took the same decision
     assert (fallbacks[0] > 0) == fallback
+
+
+def test_bench_eight_ranks_one_gpu_all_seven_seams():
+    """BASELINE config 4's shape -- 20 Msps, eight overlapped time shards, host stitch -- as the driver would launch it on an
+    8-GPU node, here with all eight ranks on cuda:0: every one of the seven seams must compare identical to a canonical
+    call over a window that straddles it."""
+    env = dict(os.environ, ADSB_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1",
+           "--log2n", "22", "--fs", "20e6", "--bursts", "3000", "--min-time", "0.02"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    mg = d["multi_gpu"]
+    assert mg["ranks_seen"] == 8 and mg["exchange_transport"] == "shm mailbox"
+    assert len(mg["seam_check"]["per_seam"]) == 7 and mg["seam_check"]["all_identical"]
+    assert all(s_["bursts_compared"] > 20 for s_ in mg["seam_check"]["per_seam"])
+    assert [r_["rank"] for r_ in mg["per_rank"]] == list(range(8))
 
 
 def test_bench_two_ranks_one_gpu_seam_check():

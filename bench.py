@@ -313,32 +313,35 @@ def extra_configs(args, dev, depth):
     return out
 
 
-def host_fed_record(args, fe, iq, fmt, depth):
-    """PCIe-inclusive rates of the host-fed entry point (adsb_submit_format_host), next to a plain pinned H2D copy of
-    the same chunks measured in the same run.  Never the bench `value`."""
+def quantise_for(fmt, iq, fe):
+    """The float [n,2] stream quantised to an integer wire format (full scale 4.0); sets the context's matching scale."""
     import torch
     from gr_adsb_amd import _native
+    if fmt == _native.FMT_SC16:
+        fe.ctx.set_format_scale(fmt, 4.0 / 32767.0)
+        return torch.clamp(torch.round(iq * (32767.0 / 4.0)), -32768, 32767).to(torch.int16).contiguous()
+    if fmt == _native.FMT_SC8:
+        fe.ctx.set_format_scale(fmt, 4.0 / 127.0)
+        return torch.clamp(torch.round(iq * (127.0 / 4.0)), -128, 127).to(torch.int8).contiguous()
+    if fmt == _native.FMT_CU8:
+        fe.ctx.set_format_scale(fmt, 4.0 / 255.0)
+        return torch.clamp(torch.floor(iq * (127.5 / 4.0) + 128.0), 0, 255).to(torch.uint8).contiguous()
+    if fmt == _native.FMT_MAG2:
+        return (iq[:, 0] * iq[:, 0] + iq[:, 1] * iq[:, 1]).contiguous()
+    return iq
+
+
+def host_fed_record(args, fe, iq, depth, formats=("fc32", "sc16", "sc8", "cu8")):
+    """PCIe-inclusive rates of the host-fed entry point (adsb_submit_format_host) per wire format, each next to a plain
+    pinned H2D copy of the same bytes measured in the same run.  Never the bench `value`."""
+    import torch
+    from gr_adsb_amd import _native
+    FM = {"fc32": _native.FMT_FC32, "sc16": _native.FMT_SC16, "sc8": _native.FMT_SC8, "cu8": _native.FMT_CU8}
     chunk = min(iq.shape[0], 1 << args.hostfed_log2n)
     nbuf = 4
-    pinned = [torch.empty((chunk, 2), dtype=torch.float32).pin_memory() for _ in range(nbuf)]
-    for k, p in enumerate(pinned):
-        p.copy_(iq[k * chunk:(k + 1) * chunk] if (k + 1) * chunk <= iq.shape[0] else iq[:chunk])
-    torch.cuda.synchronize()
-    bytes_per = chunk * 8
-    # plain pinned H2D of the same chunks, back to back on one stream
-    dst = torch.empty((chunk, 2), dtype=torch.float32, device=iq.device)
-    st = torch.cuda.Stream()
-    with torch.cuda.stream(st):
-        dst.copy_(pinned[0], non_blocking=True)
-        st.synchronize()
-        reps = 12
-        t0 = time.perf_counter()
-        for k in range(reps):
-            dst.copy_(pinned[k % nbuf], non_blocking=True)
-        st.synchronize()
-        h2d = reps * bytes_per / (time.perf_counter() - t0) / 1e9
+    out = {"entry_point": "adsb_submit_format_host, %d chunks in flight" % depth, "chunk_samples": chunk, "formats": {}}
 
-    def run(srcs, reps):
+    def run(fmt, srcs, reps):
         pend, nb = [], 0
         for k in range(2):                                 # warm: device input buffers of the slots, staging ring
             fe.ctx.wait(fe.ctx.submit_format_host(fmt, srcs[k % len(srcs)]), fetch=False)
@@ -350,29 +353,93 @@ def host_fed_record(args, fe, iq, fmt, depth):
         while pend:
             nb = fe.ctx.wait(pend.pop(0), fetch=False)
         dt = time.perf_counter() - t0
-        return reps * chunk / dt / 1e6, reps * bytes_per / dt / 1e9, nb
+        return reps * chunk / dt / 1e6, nb, dt
 
-    views = [p.numpy().view(np.complex64).reshape(-1) for p in pinned]
-    p_msps, p_gbs, nb = run(views, 12)
-    pageable = [v.copy() for v in views[:2]]
-    g_msps, g_gbs, _ = run(pageable, 6)
-    # the same pageable buffers page-locked in place (adsb_host_register: what an application does once per ring buffer)
+    for name in formats:
+        fmt = FM[name]
+        dev = [quantise_for(fmt, iq[k * chunk:(k + 1) * chunk] if (k + 1) * chunk <= iq.shape[0] else iq[:chunk], fe) for k in range(nbuf)]
+        pinned = [torch.empty(d.shape, dtype=d.dtype).pin_memory() for d in dev]
+        for p_, d in zip(pinned, dev):
+            p_.copy_(d)
+        torch.cuda.synchronize()
+        bytes_per = pinned[0].numel() * pinned[0].element_size()
+        # plain pinned H2D of the same chunks, back to back on one stream
+        dst = torch.empty_like(dev[0])
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            dst.copy_(pinned[0], non_blocking=True)
+            st.synchronize()
+            reps = 12
+            t0 = time.perf_counter()
+            for k in range(reps):
+                dst.copy_(pinned[k % nbuf], non_blocking=True)
+            st.synchronize()
+            h2d = reps * bytes_per / (time.perf_counter() - t0) / 1e9
+        dt_np, per = _native.FMT_LAYOUT[fmt]
+        views = [p_.numpy().reshape(-1).view(dt_np) if name != "fc32" else p_.numpy().view(np.complex64).reshape(-1) for p_ in pinned]
+        p_msps, nb, dt = run(fmt, views, 12)
+        p_gbs = 12 * bytes_per / dt / 1e9
+        pageable = [v.copy() for v in views[:2]]
+        g_msps, _, dt = run(fmt, pageable, 8)
+        g_gbs = 8 * bytes_per / dt / 1e9
+        rec = {"bytes_per_sample": bytes_per // chunk, "bursts_per_chunk": int(nb),
+               "pinned": {"value": round(p_msps, 1), "unit": "Msamples/s", "gbytes_per_s": round(p_gbs, 2)},
+               "pageable": {"value": round(g_msps, 1), "unit": "Msamples/s", "gbytes_per_s": round(g_gbs, 2),
+                            "vs_pinned": round(g_gbs / p_gbs, 3)},
+               "plain_pinned_h2d_gbytes_per_s": round(h2d, 2), "pinned_vs_plain_h2d": round(p_gbs / h2d, 3)}
+        if name == "fc32":
+            # the same pageable buffers page-locked in place (adsb_host_register: what an application does once per ring buffer)
+            t0 = time.perf_counter()
+            regs = [_native.RegisteredArray(a) for a in pageable]
+            t_reg = (time.perf_counter() - t0) / len(regs)
+            r_msps, _, dt = run(fmt, [r.array for r in regs], 8)
+            for r in regs:
+                r.close()
+            rec["registered_in_place"] = {"value": round(r_msps, 1), "unit": "Msamples/s", "gbytes_per_s": round(8 * bytes_per / dt / 1e9, 2),
+                                          "register_ms_per_buffer": round(t_reg * 1e3, 2),
+                                          "note": "the same pageable buffers after adsb_host_register (once per buffer)"}
+        out["formats"][name] = rec
+        del pinned, dev, dst, views, pageable
+        torch.cuda.empty_cache()
+    out["pageable_note"] = ("pageable sources are copied into a ring of four pinned 16 MiB chunks by the context's copy threads "
+                            "(adsb_set_copy_threads, default 6 incl. the caller) beside the DMA of the previous chunk")
+    # the complex64 record at the top level too (the shape earlier rounds reported)
+    out.update({k: v for k, v in out["formats"].get("fc32", {}).items() if k in ("pinned", "pageable", "registered_in_place",
+                                                                                 "plain_pinned_h2d_gbytes_per_s", "pinned_vs_plain_h2d")})
+    return out
+
+
+def host_fed_all_ranks(args, fe, iq, depth, rank, n_gpus, sync_all, ag_obj):
+    """--gpus N --host-fed: every rank feeds ITS GPU from page-locked host memory through adsb_submit_format_host at the
+    same time (one barrier in front, one behind): the PCIe-inclusive figure of the node, per rank and in total."""
+    import torch
+    from gr_adsb_amd import _native
+    chunk = min(iq.shape[0], 1 << args.hostfed_log2n)
+    pinned = [torch.empty((chunk, 2), dtype=torch.float32).pin_memory() for _ in range(3)]
+    for k, p_ in enumerate(pinned):
+        p_.copy_(iq[:chunk])
+    views = [p_.numpy().view(np.complex64).reshape(-1) for p_ in pinned]
+    reps = 12
+    for k in range(2):
+        fe.ctx.wait(fe.ctx.submit_format_host(_native.FMT_FC32, views[k]), fetch=False)
+    sync_all()
     t0 = time.perf_counter()
-    regs = [_native.RegisteredArray(a) for a in pageable]
-    t_reg = (time.perf_counter() - t0) / len(regs)
-    r_msps, r_gbs, _ = run([r.array for r in regs], 8)
-    for r in regs:
-        r.close()
-    del pinned, dst
-    return {"entry_point": "adsb_submit_format_host, %d chunks in flight" % depth, "chunk_samples": chunk,
-            "bursts_per_chunk": int(nb),
-            "pinned": {"value": round(p_msps, 1), "unit": "Msamples/s", "gbytes_per_s": round(p_gbs, 2)},
-            "pageable": {"value": round(g_msps, 1), "unit": "Msamples/s", "gbytes_per_s": round(g_gbs, 2),
-                         "note": "copied through two pinned 16 MiB chunks by one host thread, CPU copy overlapping the DMA"},
-            "registered_in_place": {"value": round(r_msps, 1), "unit": "Msamples/s", "gbytes_per_s": round(r_gbs, 2),
-                                    "register_ms_per_buffer": round(t_reg * 1e3, 2),
-                                    "note": "the same pageable buffers after adsb_host_register (once per buffer)"},
-            "plain_pinned_h2d_gbytes_per_s": round(h2d, 2), "pinned_vs_plain_h2d": round(p_gbs / h2d, 3)}
+    pend = []
+    for k in range(reps):
+        pend.append(fe.ctx.submit_format_host(_native.FMT_FC32, views[k % 3]))
+        if len(pend) == depth:
+            fe.ctx.wait(pend.pop(0), fetch=False)
+    while pend:
+        fe.ctx.wait(pend.pop(0), fetch=False)
+    own = time.perf_counter() - t0
+    sync_all()
+    wall = time.perf_counter() - t0
+    per = ag_obj({"rank": rank, "msamples_per_s": round(reps * chunk / own / 1e6, 1), "gbytes_per_s": round(reps * chunk * 8 / own / 1e9, 2)})
+    walls = ag_obj(wall)
+    return {"entry_point": "adsb_submit_format_host (complex64, page-locked source), every rank at once", "chunk_samples": chunk,
+            "chunks_per_rank": reps, "per_rank": per,
+            "total": {"value": round(n_gpus * reps * chunk / max(walls) / 1e6, 1), "unit": "Msamples/s",
+                      "gbytes_per_s": round(n_gpus * reps * chunk * 8 / max(walls) / 1e9, 2)}}
 
 
 def main():
@@ -395,6 +462,8 @@ def main():
     ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--extra-min-time", type=float, default=0.25)
     ap.add_argument("--hostfed-log2n", type=int, default=26)
+    ap.add_argument("--host-fed", action="store_true",
+                    help="with --gpus N > 1: also measure the PCIe-inclusive rate, every rank feeding its GPU from page-locked host memory")
     ap.add_argument("--mixed-df", action="store_true",
                     help="BASELINE config 5's signal as the main workload: DF mix of docs/DF_histogram.txt, SNR 3-25 dB over noise 2e-3")
     ap.add_argument("--depth", type=int, default=0, help="passes in flight (default: the library's ADSB_MAX_IN_FLIGHT)")
@@ -452,18 +521,9 @@ def main():
         iq = gen_stream_blocks(n_own, 0, fs, args.bursts, args.seed, dev, **synth)
         plan = None
         # quantise the same stream to the integer wire format (full scale 4.0); the kernel converts with the same scale
-        if fmt == _native.FMT_MAG2:
-            # |IQ|^2 of the same stream with separately rounded products, computed once outside the timed region
-            iq = (iq[:, 0] * iq[:, 0] + iq[:, 1] * iq[:, 1]).contiguous()
-        elif fmt == _native.FMT_SC16:
-            fe.ctx.set_format_scale(fmt, 4.0 / 32767.0)
-            iq = torch.clamp(torch.round(iq * (32767.0 / 4.0)), -32768, 32767).to(torch.int16).contiguous()
-        elif fmt == _native.FMT_SC8:
-            fe.ctx.set_format_scale(fmt, 4.0 / 127.0)
-            iq = torch.clamp(torch.round(iq * (127.0 / 4.0)), -128, 127).to(torch.int8).contiguous()
-        elif fmt == _native.FMT_CU8:
-            fe.ctx.set_format_scale(fmt, 4.0 / 255.0)
-            iq = torch.clamp(torch.floor(iq * (127.5 / 4.0) + 128.0), 0, 255).to(torch.uint8).contiguous()
+        # |IQ|^2 of the same stream (separately rounded products) / the stream quantised to the integer wire
+        # format (full scale 4.0; the kernel converts with the same scale), computed once outside the timed region
+        iq = quantise_for(fmt, iq, fe)
     else:
         plan = shard_plan(stream_len, n_gpus, sps, align=n_own)[rank]
         iq = gen_stream_blocks(plan["hi"] - plan["lo"], plan["lo"], fs, args.bursts, args.seed, dev, **synth)
@@ -593,6 +653,9 @@ def main():
             assert len({r["device"] for r in per_rank}) == n_gpus or len({r["pci_bus_id"] for r in per_rank}) == n_gpus, \
                 "ranks share a GPU (set ADSB_BENCH_ONE_GPU=1 if that is intended)"
         seam = seam_check(args, fe, dev, rank, n_gpus, sps, n_own, stream_len, last_kept[0], ag_obj)
+    hf_multi = None
+    if n_gpus > 1 and args.host_fed:
+        hf_multi = host_fed_all_ranks(args, fe, iq, DEPTH, rank, n_gpus, sync_all, ag_obj)
 
     result = None
     if rank == 0:
@@ -642,6 +705,8 @@ def main():
             result["multi_gpu"] = {"ranks_seen": len(per_rank), "exchange_transport": transport, "per_rank": per_rank,
                                    "stitch_fallbacks_total": int(sum(r["stitch_fallbacks"] for r in per_rank)),
                                    "seam_check": seam}
+            if hf_multi is not None:
+                result["host_fed"] = hf_multi
         if not args.no_cpu and n_gpus == 1 and not intfmt:
             n_cpu = min(n_own, 1 << args.cpu_log2n)
             host = iq[:n_cpu].cpu().numpy().view(np.complex64).reshape(-1)
@@ -676,7 +741,7 @@ def main():
                 "oracle/ref_structured.py: vectorised threshold/edges + per-PULSE Python loop + np.median, the cost "
                 "structure of framer.py:83-174 / demod.py:67-110 (|IQ|^2 given); pinned to the goldens and the real reference")
         if n_gpus == 1 and not intfmt and not args.no_hostfed:
-            result["host_fed"] = host_fed_record(args, fe, iq, fmt, DEPTH)
+            result["host_fed"] = host_fed_record(args, fe, iq, DEPTH)
         if n_gpus == 1 and not intfmt and not args.no_extra:
             del iq
             torch.cuda.empty_cache()

@@ -18,6 +18,7 @@ FLAG_TIMING = 1
 FLAG_LONG_AWARE_GATE = 2  # opt-in: the gate holds 119*sps after a burst whose first data bit is set
 FLAG_CONFIDENCE = 4       # opt-in: keep demod.bit_confidence's ratios (demod.py:97-101) for the whole-buffer entry points
 FLAG_SINGLE_STREAM = 8    # profiling aid: the sparse tail of a pass on the compute stream instead of beside the next pass
+FLAG_FRAMER_SLICES = 32   # adsb_framer_work also returns the 112 bits of tags whose burst ends inside the call's input
 FLAG_LOW_LATENCY = 16     # the tail of a pass runs beside the next pass's k_detect: results a pass earlier, 1-2 % less throughput
 ABI_VERSION = 2
 # input sample formats (include/adsb_hip.h ADSB_FMT_*): numpy dtype of the flat host array, items per sample
@@ -35,7 +36,7 @@ BURST_LONG_HINT = 0x2000 # records of a long-aware context: this burst holds the
 MAX_IN_FLIGHT = 3
 
 EXPORTS = [
-    "adsb_abi_version", "adsb_create", "adsb_destroy", "adsb_set_threshold", "adsb_set_stream", "adsb_wait_for_event", "adsb_reset", "adsb_framer_state",
+    "adsb_abi_version", "adsb_create", "adsb_destroy", "adsb_set_threshold", "adsb_set_stream", "adsb_set_copy_threads", "adsb_host_copy", "adsb_wait_for_event", "adsb_reset", "adsb_framer_state",
     "adsb_process_iq", "adsb_process_mag2", "adsb_process_iq_device", "adsb_process_mag2_device", "adsb_last_result",
     "adsb_submit_iq_device", "adsb_submit_mag2_device", "adsb_submit_iq16_device", "adsb_submit_shard_device", "adsb_wait",
     "adsb_set_iq16_scale", "adsb_process_iq16", "adsb_process_iq16_device",
@@ -91,6 +92,8 @@ def load():
     lib.adsb_set_stream.argtypes = [vp, vp]
     lib.adsb_reset.argtypes = [vp]
     lib.adsb_wait_for_event.argtypes = [vp, vp]
+    lib.adsb_set_copy_threads.argtypes = [vp, i32]
+    lib.adsb_host_copy.argtypes = [vp, vp, vp, c.c_size_t]
     lib.adsb_framer_state.argtypes = [vp, c.POINTER(c.c_float), c.POINTER(c.c_int64)]
     lib.adsb_set_iq16_scale.argtypes = [vp, f32]
     lib.adsb_submit_iq16_device.argtypes = [vp, vp, i64, i64, c.POINTER(i32)]
@@ -295,6 +298,15 @@ class Context:
             # the host buffer of a host-fed submission was only kept alive for the upload: let go of it now, also on error
             getattr(self, "_host_keepalive", {}).pop(int(ticket), None)
         return self.last_result(copy=copy) if fetch else n_out.value
+
+    def set_copy_threads(self, threads):
+        """Host threads copying pageable host-fed sources into the pinned ring (before the first such submission)."""
+        self._chk(self.lib.adsb_set_copy_threads(self._h, int(threads)))
+
+    def host_copy(self, dst, src):
+        """dst[:] = src for two contiguous host arrays of equal size, split over the context's copy threads."""
+        assert dst.nbytes == src.nbytes and dst.flags.c_contiguous and src.flags.c_contiguous
+        self._chk(self.lib.adsb_host_copy(self._h, ctypes.c_void_p(dst.ctypes.data), ctypes.c_void_p(src.ctypes.data), dst.nbytes))
 
     def wait_for_event(self, hip_event):
         """Everything submitted next runs after this hipEvent_t (raw handle) has completed: device-side ordering."""

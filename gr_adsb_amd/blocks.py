@@ -40,8 +40,14 @@ def make_pdu(start_timestamp, fs, offset, snr, bits112):
 class framer(gr.sync_block):
     """ADS-B preamble detector / tagger (reference python/adsb/framer.py:33-182)."""
 
-    def __init__(self, fs, threshold, device=0, improved=False, long_aware=False):
-        """improved (extension; default off = the reference's behaviour bit for bit): the tags no
+    def __init__(self, fs, threshold, device=0, improved=False, long_aware=False, min_chunk=0):
+        """min_chunk (extension, default 0 = whatever the scheduler hands over, like the reference): when > 0 the block asks
+        the scheduler for work() calls of a multiple of that many items (gr.basic_block.set_output_multiple): a call costs
+        tens of microseconds whatever its size, so large chunks are what lifts the block from tens of Msamples/s to
+        Gsamples/s (tools/gr_latency.py).  Chunking is the scheduler's freedom in the reference too (framer.py:72-77);
+        results under any chunking equal the reference's under the same chunking.
+
+        improved (extension; default off = the reference's behaviour bit for bit): the tags no
         longer depend on how the scheduler chunks the stream -- pulses straddling a work() boundary are evaluated
         (framer.py:98-108 drops them), the re-trigger state never goes stale (framer.py:177-179) -- and equal those of
         ONE reference work() call over the whole stream.  Price: the block delays its output by `self.delay` samples
@@ -72,8 +78,15 @@ class framer(gr.sync_block):
             self._eob = _native.EOB_NONE                  # end-of-burst state carried between calls (stream offsets)
         self.set_history(self.N_hist)
         self.set_tag_propagation_policy(gr.TPP_ONE_TO_ONE)
+        if min_chunk:
+            self.set_output_multiple(int(min_chunk))
+        # the framer's device pass also slices the bits of every burst that ends inside its chunk: a demod paired with
+        # this block (demod(fs, framer=this)) publishes them without a second upload / device pass of the same samples
         self._ctx = _native.Context(fs, threshold, device=device,
-                                    flags=_native.FLAG_LONG_AWARE_GATE if self.long_aware else 0)
+                                    flags=(_native.FLAG_LONG_AWARE_GATE if self.long_aware else 0) |
+                                          (0 if self.improved else _native.FLAG_FRAMER_SLICES))
+        self._sliced = {}                 # tag offset -> (bits14, flags) of the tags this block emitted with bits
+        self._sliced_cap = 8192
 
     def set_threshold(self, threshold):
         self.threshold = threshold            # read once per work(), like the reference (framer.py:84)
@@ -128,6 +141,12 @@ class framer(gr.sync_block):
             return self._work_improved(in0, out0)
         bursts = self._ctx.framer_work(in0[:N + self.N_hist - 1], N, self.nitems_written(0))
         snr = _native.snr_db(bursts["peak"], bursts["median"]) if len(bursts) else ()     # (most work() calls carry no burst)
+        if len(bursts):
+            if len(self._sliced) > self._sliced_cap:      # nobody collects them (no paired demod): forget the oldest
+                for k in sorted(self._sliced)[:len(self._sliced) - self._sliced_cap // 2]:
+                    del self._sliced[k]
+            for b in bursts[(bursts["flags"] & _native.BURST_DEMOD) != 0]:
+                self._sliced[int(b["offset"])] = (b["bits"].copy(), int(b["flags"]))
         for b, s in zip(bursts, snr):
             self.add_item_tag(
                 0,
@@ -136,8 +155,16 @@ class framer(gr.sync_block):
                 pmt.to_pmt(("SOB", float(s) if HAVE_GNURADIO else s)),
                 pmt.to_pmt("framer"),
             )
-        out0[:] = in0[self.N_hist - 1:]
+        _passthrough(self._ctx, out0, in0[self.N_hist - 1:])
         return N
+
+
+def _passthrough(ctx, out0, src):
+    """out0[:] = src (framer.py:181, demod.py:135); multi-megabyte chunks through the library's copy threads."""
+    if out0.nbytes >= (4 << 20) and out0.flags.c_contiguous and src.flags.c_contiguous and src.dtype == out0.dtype:
+        ctx.host_copy(out0, src)
+    else:
+        out0[:] = src
 
 
 _DF_WEIGHTS = np.array([16, 8, 4, 2, 1])
@@ -155,8 +182,17 @@ def _prefilter_pass(flags, df):
 class demod(gr.sync_block):
     """PPM bit slicer / PDU publisher (reference python/adsb/demod.py:31-136)."""
 
-    def __init__(self, fs, device=0, parity_filter=False, improved=False):
-        """improved (extension; default off): a burst that straddles the end of a work() chunk is
+    def __init__(self, fs, device=0, parity_filter=False, improved=False, framer=None, min_chunk=0):
+        """framer (extension, default None = an independent block, like the reference's): the framer block of the same
+        flowgraph whose output feeds this block.  That framer's device pass has already sliced the bits of every burst
+        that ends inside its chunk; a paired demod publishes those PDUs straight from the framer's records -- the same
+        samples are not uploaded and scanned a second time -- and only goes to the device itself for a burst that was
+        incomplete in the framer's chunk but is complete in its own.  The drop rule (demod.py:82) is applied to THIS
+        block's chunk either way, so the PDU set under any pair of schedules equals the reference's.  In paired mode
+        `bit_confidence` (demod.py:101, never published) is only maintained when `want_confidence` is set.
+        min_chunk: see framer.
+
+        improved (extension; default off): a burst that straddles the end of a work() chunk is
         completed with the next chunk's samples instead of being dropped for good (demod.py:61-64,130-133 is a stub
         that never completes it); with a 3-element tag value from the improved framer the PDU timestamp uses the
         undelayed input offset.
@@ -182,8 +218,13 @@ class demod(gr.sync_block):
         self.bits = []
         self.bit_idx = 0
         self.straddled_packet = 0
-        self.want_confidence = True           # demod.py:101 computes it on every burst
+        self._framer = framer
+        if framer is not None and (framer.improved or self.improved):
+            raise ValueError("framer= pairing is for the reference-exact blocks (improved=False on both)")
+        self.want_confidence = framer is None  # demod.py:101 computes it on every burst
         self.set_tag_propagation_policy(gr.TPP_ONE_TO_ONE)
+        if min_chunk:
+            self.set_output_multiple(int(min_chunk))
         self.message_port_register_out(pmt.to_pmt("demodulated"))
         self._ctx = _native.Context(fs, 0.0, device=device)
 
@@ -198,9 +239,27 @@ class demod(gr.sync_block):
             self._work_improved(in0, nread, tags)
         elif len(tags):
             offs = np.array([t.offset for t in tags], dtype=np.int64)
-            # demod.py:79 indexes with nitems_written(0); equal to nitems_read(0) for this sync block
-            bits, ok, ratio = self._ctx.demod_work(in0, self.nitems_written(0), offs, want_ratio=self.want_confidence)
-            pf = self._ctx.last_demod_flags
+            sliced = None
+            if self._framer is not None and not self.want_confidence:
+                # bits the paired framer's pass already holds; this block's own drop rule (demod.py:76,82)
+                end = self.nitems_written(0) + len(in0)
+                fits = offs + 119 * self.sps + self.sps // 2 < end
+                got = [self._framer._sliced.pop(int(o), None) for o in offs]
+                if all((g is not None) or (not f) for g, f in zip(got, fits)):
+                    sliced = got
+            if sliced is not None:
+                ok = fits
+                bits = np.zeros((len(offs), 112), dtype=np.uint8)
+                pf = np.zeros(len(offs), dtype=np.uint8)
+                for i, g in enumerate(sliced):
+                    if ok[i]:
+                        bits[i] = np.unpackbits(g[0])[:112]
+                        pf[i] = g[1] & 0xFF
+                ratio = None
+            else:
+                # demod.py:79 indexes with nitems_written(0); equal to nitems_read(0) for this sync block
+                bits, ok, ratio = self._ctx.demod_work(in0, self.nitems_written(0), offs, want_ratio=self.want_confidence)
+                pf = self._ctx.last_demod_flags
             for i, tag in enumerate(tags):
                 if not ok[i]:
                     self.straddled_packet = 1     # demod.py:130-133: dropped
@@ -216,7 +275,7 @@ class demod(gr.sync_block):
                         self.bit_confidence = np.float32(10.0) * np.log10(ratio[i])
                 self.message_port_pub(pmt.to_pmt("demodulated"),
                                       make_pdu(self.start_timestamp, self.fs, tag.offset, snr, self.bits))
-        out0[:] = in0
+        _passthrough(self._ctx, out0, in0)
         return len(out0)
 
     def _work_improved(self, in0, nread, tags):

@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, "libadsb_hip.so")
 SOURCES = ["adsb_hip.hip"]
 DEPS = ["adsb_hip.hip", "adsb_device.h", "adsb_plan.h", os.path.join("..", "..", "include", "adsb_hip.h")]
 # -ffp-contract=off: |IQ|^2 must be two rounded products and one rounded add
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread"]
 
 
 def hipcc():

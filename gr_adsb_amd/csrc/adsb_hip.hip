@@ -12,7 +12,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
 
 // wavefront-level ordering point used by adsb_device.h: LDS traffic of one wavefront is executed in
 // program order by the hardware, this only stops the compiler from moving LDS accesses across it
@@ -146,6 +150,67 @@ struct Slot {
 
 }  // namespace
 
+// Host threads that copy a pageable source into the pinned staging ring of a host-fed submission: one host core moves
+// ~10 GB/s, the DMA behind it 57 -- so the copy of every chunk is split over a few threads (created on the first pageable
+// submission, parked on a condition variable in between).
+struct CopyPool {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv_job, cv_done;
+  const char* src = nullptr;
+  char* dst = nullptr;
+  size_t bytes = 0;
+  unsigned gen = 0;
+  int pending = 0;
+  bool stop = false;
+  int nthreads = 0;      // workers besides the caller
+
+  static void slice(size_t bytes, int parts, int i, size_t* lo, size_t* hi) {
+    const size_t per = ((bytes / (size_t)parts) + 4095) & ~(size_t)4095;
+    *lo = per * (size_t)i < bytes ? per * (size_t)i : bytes;
+    *hi = (i == parts - 1) ? bytes : (*lo + per < bytes ? *lo + per : bytes);
+  }
+  void worker(int id) {
+    unsigned seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(m);
+      cv_job.wait(lk, [&] { return stop || gen != seen; });
+      if (stop) return;
+      seen = gen;
+      const char* s_ = src; char* d_ = dst; const size_t b_ = bytes;
+      lk.unlock();
+      size_t lo, hi;
+      slice(b_, nthreads + 1, id + 1, &lo, &hi);
+      if (hi > lo) memcpy(d_ + lo, s_ + lo, hi - lo);
+      lk.lock();
+      if (--pending == 0) cv_done.notify_one();
+    }
+  }
+  void start(int n) {
+    nthreads = n;
+    for (int i = 0; i < n; ++i) th.emplace_back([this, i] { worker(i); });
+  }
+  // blocking: returns when all of [src, src + bytes) is in dst
+  void copy(char* d_, const char* s_, size_t b_) {
+    if (nthreads == 0 || b_ < ((size_t)1 << 20)) { memcpy(d_, s_, b_); return; }
+    {
+      std::lock_guard<std::mutex> lk(m);
+      src = s_; dst = d_; bytes = b_; pending = nthreads; ++gen;
+    }
+    cv_job.notify_all();
+    size_t lo, hi;
+    slice(b_, nthreads + 1, 0, &lo, &hi);
+    memcpy(d_ + lo, s_ + lo, hi - lo);
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return pending == 0; });
+  }
+  ~CopyPool() {
+    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    cv_job.notify_all();
+    for (std::thread& t : th) t.join();
+  }
+};
+
 struct adsb_ctx {
   int device = 0;
   double fs = 0;
@@ -177,10 +242,13 @@ struct adsb_ctx {
   size_t h_stage_cap = 0;
   void* h_dm = nullptr;      // pinned scratch of adsb_demod_work: tag positions in, bits / ok / ratio out
   size_t h_dm_cap = 0;
-  void* h_ring[2] = {nullptr, nullptr};   // pinned chunks for pageable host-fed submissions (double buffered)
-  hipEvent_t ring_done[2] = {nullptr, nullptr};
-  bool ring_used[2] = {false, false};
+  static constexpr int kRing = 4;
+  void* h_ring[kRing] = {nullptr, nullptr, nullptr, nullptr};   // pinned chunks for pageable host-fed submissions
+  hipEvent_t ring_done[kRing] = {nullptr, nullptr, nullptr, nullptr};
+  bool ring_used[kRing] = {false, false, false, false};
   unsigned ring_k = 0;
+  CopyPool* pool = nullptr;    // host copy threads of the pageable path (adsb_set_copy_threads; created on first use)
+  int copy_threads = -1;       // -1 = default
   adsb_stats stats{};
   char err[256] = {0};
 };
@@ -525,6 +593,36 @@ const void* device_alias(const void* host) {
   return dev;
 }
 
+int ensure_pool(adsb_ctx* c) {
+  if (c->pool) return 0;
+  c->pool = new (std::nothrow) CopyPool();
+  if (!c->pool) return fail(c, -ENOMEM, "copy pool");
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int nt = c->copy_threads >= 0 ? c->copy_threads : (hw >= 16 ? 5 : (hw >= 4 ? 2 : 0));     // workers besides the caller
+  c->pool->start(nt);
+  return 0;
+}
+
+// Pageable host memory -> device memory on `stream` through the ring of pinned chunks: the host copy of chunk k+1 (split
+// over the context's copy threads) runs beside the DMA of chunk k.  Returns once the last DMA is QUEUED.
+int staged_copy(adsb_ctx* c, void* d_dst, const void* host, size_t bytes, hipStream_t stream) {
+  constexpr size_t kChunk = (size_t)16 << 20;
+  for (void*& r : c->h_ring)
+    if (!r) HIPCHK(c, hipHostMalloc(&r, kChunk, hipHostMallocDefault));
+  int rc = ensure_pool(c);
+  if (rc) return rc;
+  for (size_t off = 0; off < bytes; off += kChunk) {
+    const size_t m = bytes - off < kChunk ? bytes - off : kChunk;
+    const int b = (int)(c->ring_k++ % (unsigned)adsb_ctx::kRing);
+    if (c->ring_used[b]) HIPCHK(c, hipEventSynchronize(c->ring_done[b]));      // the chunk's previous DMA has read it
+    c->pool->copy((char*)c->h_ring[b], (const char*)host + off, m);
+    HIPCHK(c, hipMemcpyAsync((char*)d_dst + off, c->h_ring[b], m, hipMemcpyHostToDevice, stream));
+    HIPCHK(c, hipEventRecord(c->ring_done[b], stream));
+    c->ring_used[b] = true;
+  }
+  return 0;
+}
+
 // Host buffer -> something the kernels can read, for the blocking entry points (the buffer only has to stay valid until
 // the call returns).  Large inputs are copied to the device: page-locked sources (adsb_host_alloc, hipHostMalloc, torch
 // pin_memory) go straight over PCIe, pageable ones through the context's pinned staging buffer.  Small inputs (the GNU
@@ -537,6 +635,13 @@ int upload(adsb_ctx* c, const void* host, size_t bytes, void** d_out) {
   const bool pinned = is_pinned_host(host);
   const bool small = bytes <= kZeroCopyBytes;
   const void* alias = (pinned && small) ? device_alias(host) : nullptr;     // only the in-place path needs it
+  if (!small && !pinned && bytes >= ((size_t)4 << 20)) {
+    // multi-megabyte pageable input (a GNU Radio block run with large chunks): chunked through the pinned ring
+    if ((rc = ensure(c, c->d_in, bytes + 64))) return rc;
+    if ((rc = staged_copy(c, c->d_in.p, host, bytes, c->stream))) return rc;
+    *d_out = c->d_in.p;
+    return 0;
+  }
   if (!pinned || (small && (!alias || ((uintptr_t)alias & 15u) != 0))) {
     if ((rc = ensure_pinned(c, c->h_stage, c->h_stage_cap, bytes))) return rc;
     memcpy(c->h_stage, host, bytes);
@@ -650,6 +755,7 @@ void adsb_destroy(adsb_ctx* c) {
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_dm) (void)hipHostFree(c->h_dm);
   for (void* r : c->h_ring) if (r) (void)hipHostFree(r);
+  delete c->pool;
   for (hipEvent_t e : c->ring_done) if (e) (void)hipEventDestroy(e);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
@@ -670,6 +776,21 @@ int adsb_set_stream(adsb_ctx* c, void* hip_stream) {
   if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
   c->stream = (hipStream_t)hip_stream;
   c->own_stream = false;
+  return 0;
+}
+
+int adsb_set_copy_threads(adsb_ctx* c, int32_t threads) {
+  if (!c || threads < 1 || threads > 64) return -EINVAL;
+  if (c->pool) return fail(c, -EBUSY, "copy threads already running (set before the first pageable submission)");
+  c->copy_threads = threads - 1;                            // the calling thread is one of them
+  return 0;
+}
+
+int adsb_host_copy(adsb_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c || (bytes > 0 && (!dst || !src))) return -EINVAL;
+  int rc = ensure_pool(c);
+  if (rc) return rc;
+  c->pool->copy((char*)dst, (const char*)src, bytes);
   return 0;
 }
 
@@ -786,26 +907,15 @@ static int submit_canonical(adsb_ctx* c, int mode, const void* d_data, int64_t n
 }
 
 // Host buffer -> the slot's own device input buffer on the upload stream; only this slot's k_detect waits for it.
-// Page-locked sources are DMA'd where they lie; pageable ones go through two pinned chunks, the CPU copy of chunk k+1
-// running beside the DMA of chunk k.
+// Page-locked sources are DMA'd where they lie; pageable ones go through a ring of four pinned chunks: the host copy of
+// chunk k+1 (split over the context's copy threads) runs beside the DMA of chunk k.
 static int upload_async(adsb_ctx* c, Slot& s, const void* host, size_t bytes) {
   int rc;
   if ((rc = ensure(c, s.d_in, bytes + 64))) return rc;
   if (is_pinned_host(host)) {
     HIPCHK(c, hipMemcpyAsync(s.d_in.p, host, bytes, hipMemcpyHostToDevice, c->h2d_stream));
-  } else {
-    constexpr size_t kChunk = (size_t)16 << 20;
-    for (void*& r : c->h_ring)
-      if (!r) HIPCHK(c, hipHostMalloc(&r, kChunk, hipHostMallocDefault));
-    for (size_t off = 0; off < bytes; off += kChunk) {
-      const size_t m = bytes - off < kChunk ? bytes - off : kChunk;
-      const int b = c->ring_k++ & 1;
-      if (c->ring_used[b]) HIPCHK(c, hipEventSynchronize(c->ring_done[b]));      // the chunk's previous DMA has read it
-      memcpy(c->h_ring[b], (const char*)host + off, m);
-      HIPCHK(c, hipMemcpyAsync((char*)s.d_in.p + off, c->h_ring[b], m, hipMemcpyHostToDevice, c->h2d_stream));
-      HIPCHK(c, hipEventRecord(c->ring_done[b], c->h2d_stream));
-      c->ring_used[b] = true;
-    }
+  } else if ((rc = staged_copy(c, s.d_in.p, host, bytes, c->h2d_stream))) {
+    return rc;
   }
   HIPCHK(c, hipEventRecord(s.h2d_done, c->h2d_stream));
   HIPCHK(c, hipStreamWaitEvent(c->stream, s.h2d_done, 0));
@@ -878,6 +988,7 @@ int adsb_framer_work(adsb_ctx* c, const float* in0, int64_t n_in0, int64_t N, in
   int rc = upload(c, in0, (size_t)n_in0 * 4, &d);
   if (rc) return rc;
   Plan pl = plan_framer_work(d, n_in0, N, nitems_written, c->sps, c->st);
+  if (c->flags & ADSB_FLAG_FRAMER_SLICES) pl.dem_hi = n_in0;   // bursts that end inside this call's input get their bits
   Summary s;
   int32_t nres = 0;
   rc = run_pipeline(c, pl, &s, &nres);

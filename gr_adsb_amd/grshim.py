@@ -42,6 +42,12 @@ class sync_block:
     def set_tag_propagation_policy(self, p):
         self._tpp = p
 
+    def set_output_multiple(self, n):
+        self._output_multiple = int(n)
+
+    def output_multiple(self):
+        return getattr(self, "_output_multiple", 1)
+
     def nitems_written(self, port):
         return self._nwritten
 

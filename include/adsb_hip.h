@@ -69,6 +69,11 @@ extern "C" {
  * the GPU BESIDE the next pass's streaming kernel instead of after it: results arrive about one pass earlier and two
  * calls in flight suffice, for 1-2 % less throughput.  Default off = maximum throughput. */
 #define ADSB_FLAG_LOW_LATENCY 16u
+/* adsb_framer_work also slices the 112 bits of every tag whose burst ends inside the call's input
+ * (offset + 119*sps + sps/2 < nitems_written + N, the rule of demod.py:82 applied to the framer's own chunk): such tags
+ * come back with ADSB_BURST_DEMOD, bits and the parity pre-filter flags -- the one device pass a framer/demod pair of
+ * one flowgraph needs (gr_adsb_amd.blocks.demod(fs, framer=...)); default off: tags carry offset / peak / median only. */
+#define ADSB_FLAG_FRAMER_SLICES 32u
 
 /* adsb_burst.flags */
 #define ADSB_BURST_DEMOD 1u /* eob inside the demod input: bits[] valid, a PDU is published (demod.py:82) */
@@ -125,6 +130,13 @@ int adsb_set_threshold(adsb_ctx* ctx, float threshold);
  * buffer first.  -EBUSY while submitted calls are pending.  A context is used from one thread at a time;
  * different contexts are independent. */
 int adsb_set_stream(adsb_ctx* ctx, void* hip_stream);
+/* Host threads (1..64, the caller included) that copy PAGEABLE sources of adsb_submit_format_host into the pinned staging
+ * ring; default 6 on hosts with >= 16 cpus.  Before the first pageable submission only (-EBUSY afterwards).  Page-locked
+ * sources (adsb_host_alloc, adsb_host_register) never touch these threads: they are DMA'd where they lie. */
+int adsb_set_copy_threads(adsb_ctx* ctx, int32_t threads);
+/* memcpy split over the context's copy threads (the GNU Radio passthrough `out0[:] = in0` of multi-megabyte chunks:
+ * framer.py:181, demod.py:135).  Plain host memory on both sides; blocking. */
+int adsb_host_copy(adsb_ctx* ctx, void* dst, const void* src, size_t bytes);
 /* Order everything submitted to this context AFTER a HIP event of the caller (hipEvent_t recorded on the stream that
  * produces a device-resident input, e.g. a framework's current stream): a device-side dependency, the host does not
  * wait.  The event may be destroyed once the next call on the context has returned. */

@@ -196,6 +196,50 @@ def test_dropin_blocks_match_reference_goldens(native, name, sched):
             assert np.array_equal(cf.view(np.uint32), single[o])
 
 
+@pytest.mark.parametrize("name", golden_names() + large_golden_names()[:2])
+def test_paired_demod_publishes_the_framers_slices(native, name):
+    """demod(fs, framer=fr): the framer's ONE device pass per chunk also slices the bits (ADSB_FLAG_FRAMER_SLICES), the demod
+    publishes them without uploading / scanning the samples again.  Same tags and PDUs as the reference under every stored
+    schedule, and -- framer and demod chunked differently -- the same PDUs as the unpaired blocks under the same pair of
+    schedules (the drop rule is the demod's own chunk end, demod.py:82)."""
+    from gr_adsb_amd import blocks, grshim
+    g = Golden(name)
+    calls = []
+    for sched in schedules_of(name):
+        fr = blocks.framer(g.fs, g.thr, min_chunk=64)
+        dm = blocks.demod(g.fs, framer=fr)
+        assert fr.output_multiple() == 64 and dm.output_multiple() == 1
+        dm.start_timestamp = 0.0
+        real = dm._ctx.demod_work
+        dm._ctx.demod_work = lambda *a, **k: (calls.append(sched), real(*a, **k))[1]
+        tags, msgs = grshim.drive(fr, dm, g.x, None if sched == "single" else g.sched(sched))
+        assert np.array_equal(np.array([t.offset for t in tags], dtype=np.int64), g.get(sched, "tag_offsets"))
+        offs = np.array([int(round(m[0]["timestamp"] * g.fs)) for _, m in msgs], dtype=np.int64)
+        assert np.array_equal(offs, g.get(sched, "pdu_offsets"))
+        assert np.array_equal(np.array([m[1] for _, m in msgs], dtype=np.uint8).reshape(-1, 112), g.pdu_bits(sched))
+        psnr = np.array([m[0]["snr"] for _, m in msgs], dtype=np.float32)
+        assert np.array_equal(psnr.view(np.uint32), g.get(sched, "pdu_snr_bits"))
+    assert not calls, "same chunking on both blocks: the paired demod never needs the device"
+    # different chunking: framer in 4096-sample calls, demod in random ones (and the other way round)
+    rng = np.random.default_rng(11)
+    n = len(g.x)
+    rnd, rem = [], n
+    while rem > 0:
+        c = int(min(rem, rng.integers(500, 9000)))
+        rnd.append(c)
+        rem -= c
+    fixed = [4096] * (n // 4096) + ([n % 4096] if n % 4096 else [])
+    for fs_, ds_ in ((fixed, rnd), (rnd, fixed)):
+        out = []
+        for paired in (False, True):
+            fr = blocks.framer(g.fs, g.thr)
+            dm = blocks.demod(g.fs, framer=fr if paired else None)
+            dm.start_timestamp = 0.0
+            _, msgs = grshim.drive(fr, dm, g.x, fs_, ds_)
+            out.append([(int(round(m[0]["timestamp"] * g.fs)), bytes(m[1]), np.float32(m[0]["snr"]).tobytes()) for _, m in msgs])
+        assert out[0] == out[1] and len(out[0]) >= 1
+
+
 @pytest.mark.parametrize("name", golden_names())
 @pytest.mark.parametrize("sched", ["fixed4096", "random", "tiny"])
 def test_improved_blocks_are_chunk_invariant(native, name, sched):

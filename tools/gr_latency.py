@@ -1,5 +1,7 @@
-"""Per-work()-call cost of the drop-in blocks (GNU Radio emulation path): one H2D copy + one device pass per
-call.  Prints the sustainable sample rate for typical scheduler chunk sizes.  GPU box only."""
+"""Per-work()-call cost of the drop-in blocks (GNU Radio emulation path) and the sample rate they sustain per chunk size,
+from scheduler-sized chunks (2 k samples) to 16 M samples: independent blocks (each uploads and scans its input: the
+reference's structure) and the paired form demod(fs, framer=...) (one upload and one device pass per chunk).  GPU box only.
+    python tools/gr_latency.py [fs]"""
 import os
 import sys
 import time
@@ -8,36 +10,43 @@ import numpy as np
 import torch  # noqa: F401
 from gr_adsb_amd import blocks, modulator as M
 
-fs = 2e6
-x = M.mag2(M.synth_iq(1 << 21, fs, 1000, 3))
-H = 16
+fs = float(sys.argv[1]) if len(sys.argv) > 1 else 2e6
+sps = int(fs // 1e6)
+L = 1 << 25
+x = M.mag2(M.synth_iq(1 << 22, fs, 1000, 3))
+x = np.tile(x, L // len(x))
+H = 8 * sps
 buf = np.concatenate([np.zeros(H - 1, np.float32), x])
-for N in (2048, 8192, 32768, 262144):
-    fr = blocks.framer(fs, 0.01)
-    dm = blocks.demod(fs)
-    out = np.empty(N, np.float32)
-    tf = td = 0.0
-    calls = samples = 0
-    for rep in range(-1, max(1, 64 * N // len(x))):           # rep -1: untimed warm-up (allocations of a fresh context)
+print("# fs %g Msps, 1000 bursts/s, host buffers (pageable numpy arrays, as GNU Radio hands them over)" % (fs / 1e6))
+for paired in (False, True):
+    for N in (2048, 8192, 32768, 262144, 1 << 20, 1 << 22, 1 << 24):
+        fr = blocks.framer(fs, 0.01)
+        dm = blocks.demod(fs, framer=fr if paired else None)
+        out = np.empty(N, np.float32)
+        tf = td = 0.0
+        calls = samples = pdus = 0
+        budget = max(2, min(1024, (1 << 26) // N))
         pos = 0
-        while pos + N <= len(x):
+        for k in range(-3, budget):                       # the first calls warm a fresh context up (allocations)
+            if pos + N > len(x):
+                pos = 0
             fr._nread = fr._nwritten = pos
             t1 = time.perf_counter()
             fr.work([buf[pos:pos + N + H - 1]], [out])
             t2 = time.perf_counter()
-            dm.tags_in = [t for t in fr.tags_out[-256:] if t.offset >= pos]       # the tags of this chunk
+            dm.tags_in = [t for t in fr.tags_out if t.offset >= pos]       # the tags of this chunk
             dm._nread = dm._nwritten = pos
             dm.work([x[pos:pos + N]], [out])
             t3 = time.perf_counter()
             pos += N
-            if rep >= 0:
+            if k >= 0:
                 tf += t2 - t1
                 td += t3 - t2
                 calls += 1
                 samples += N
-            elif pos >= 4 * N:
-                break
-        fr.tags_out.clear()
-        dm.messages.clear()
-    print("chunk %7d samples: %.3f ms per framer+demod call pair (framer %.3f, demod %.3f; %d pairs) -> %.1f Msamples/s sustained"
-          % (N, (tf + td) / calls * 1e3, tf / calls * 1e3, td / calls * 1e3, calls, samples / (tf + td) / 1e6))
+                pdus += len(dm.messages)
+            fr.tags_out.clear()
+            dm.messages.clear()
+        print("%s chunk %8d samples: %8.3f ms per framer+demod call pair (framer %.3f, demod %.3f; %d pairs, %d PDUs) -> %8.1f Msamples/s"
+              % ("paired     " if paired else "independent", N, (tf + td) / calls * 1e3, tf / calls * 1e3, td / calls * 1e3, calls, pdus,
+                 samples / (tf + td) / 1e6), flush=True)

@@ -53,15 +53,16 @@ def gen_stream_blocks(n_local, origin, fs, bursts_per_s, seed, device, block=1 <
     return out
 
 
-def pmc_traffic(fs, log2n, bursts):
-    """HBM bytes per k_detect launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json), if this
-    exact workload was profiled; PMC collection needs its own rocprofv3 run, it cannot happen inside bench.py."""
+def pmc_traffic(fmt_name, fs, bursts, mixed, log2n):
+    """HBM bytes per k_detect launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json), if this exact
+    workload was profiled; PMC collection needs its own rocprofv3 run, it cannot happen inside bench.py."""
+    key = "%s|fs=%g|bursts=%g|mixed=%d|log2n=%d" % (fmt_name, fs, bursts, int(bool(mixed)), log2n)
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            for e in json.load(f)["entries"]:
-                if e["fs"] == fs and e["log2n"] == log2n and e["bursts"] == bursts:
-                    return int(e["traffic_bytes"]), e.get("source")
-    except (OSError, ValueError, KeyError):
+            e = json.load(f)["entries"].get(key)
+        if e:
+            return int(e["traffic_bytes"]), e.get("source")
+    except (OSError, ValueError, KeyError, AttributeError):
         pass
     return None, None
 
@@ -277,6 +278,9 @@ def extra_configs(args, dev, depth):
                "longrun_calls": int(st["longrun_calls"]), "retries": int(st["retries"]),
                "long_pulses_per_step": round(st["longrun_pulses"] / max(1, st["calls"]), 2),
                "roofline": roofline_of(st, "fc32", iso_ms)}
+        tr, tr_src = pmc_traffic("fc32", fs, sp["bursts"], bool(sp["synth"]), log2n)
+        rec["roofline"]["traffic"] = tr
+        rec["roofline"]["traffic_source"] = tr_src or "none for this workload (see profiles/)"
         # parity: the GPU pass over the first 2^26 samples against the scalar C port of the reference path
         host = iq[:cpu_n].cpu().numpy().view(np.complex64).reshape(-1)
         t0 = time.perf_counter()
@@ -309,6 +313,53 @@ def extra_configs(args, dev, depth):
                               "bursts": int(len(whole))}
         out.append(rec)
         del iq, fe
+        torch.cuda.empty_cache()
+    return out
+
+
+def format_legs(args, dev, depth):
+    """The other input formats on the headline signal (BASELINE config 2: 2 Msps, ~1 k DF17 bursts/s) at 2^28 samples:
+    float32 |IQ|^2 (the framer's literal input), int16 IQ, int8 IQ, RTL-SDR uint8 IQ -- each with its own roofline record
+    (algorithmic bytes = samples x bytes per sample of THAT format) and its own parity check against the C oracle fed
+    with the oracle's exact conversion of the same bytes."""
+    import torch
+    from gr_adsb_amd import _native
+    from gr_adsb_amd.frontend import FrontEnd
+    from oracle import adsb_oracle as O
+    from oracle import c_oracle as C
+    log2n = args.extra_log2n
+    n, cpu_n = 1 << log2n, 1 << 25
+    fs, sps = 2e6, 2
+    base = gen_stream_blocks(n, 0, fs, 1000.0, args.seed, dev)
+    torch.cuda.synchronize()
+    out = []
+    for name, fmt, scale in (("mag2", _native.FMT_MAG2, None), ("sc16", _native.FMT_SC16, 4.0 / 32767.0),
+                             ("sc8", _native.FMT_SC8, 4.0 / 127.0), ("cu8", _native.FMT_CU8, 4.0 / 255.0)):
+        fe = FrontEnd(fs, args.threshold, device=dev.index, timing=True)
+        q = quantise_for(fmt, base, fe)
+        torch.cuda.synchronize()
+        ms, times, st, nb, iso_ms = run_single_gpu_config(fe, fmt, q, n, args.extra_steps, 3, args.extra_min_time, depth)
+        rec = {"name": "format_" + name, "format": name, "bytes_per_sample": _native.FMT_BYTES[fmt],
+               "workload": "BASELINE config 2's signal as %s; 2^%d samples per step resident in HBM" % (
+                   {"mag2": "float32 |IQ|^2", "sc16": "int16 IQ", "sc8": "int8 IQ", "cu8": "uint8 offset-binary IQ"}[name], log2n),
+               "value": round(n / ms / 1e3, 1), "unit": "Msamples/s", "ms_per_step": round(ms, 4), "bursts_per_step": int(nb),
+               "roofline": roofline_of(st, name, iso_ms)}
+        tr, tr_src = pmc_traffic(name, fs, 1000.0, False, log2n)
+        rec["roofline"]["traffic"] = tr
+        rec["roofline"]["traffic_source"] = tr_src or "none for this workload (see profiles/)"
+        host = q[:cpu_n].cpu().numpy()
+        if name == "mag2":
+            x = host.reshape(-1)
+        elif name == "sc16":
+            x = O.mag2_iq16(host.reshape(-1), scale)
+        else:
+            x = O.mag2_iq8(host.reshape(-1), float(np.float32(scale)), name == "cu8")
+        crecs = C.canonical(x, sps, np.float32(args.threshold))
+        grecs = fe.ctx.process_format_device(fmt, q.data_ptr(), cpu_n)
+        rec["bit_match"] = {"sample_bursts": int(len(crecs)), "identical": recs_match(grecs, crecs),
+                            "sample": "first 2^25 samples vs oracle/adsb_oracle.c on the oracle's conversion of the same bytes"}
+        out.append(rec)
+        del q, fe
         torch.cuda.empty_cache()
     return out
 
@@ -661,7 +712,7 @@ def main():
     if rank == 0:
         total_samples = float(n_own) * n_gpus * args.steps
         value = total_samples / elapsed / 1e6
-        traffic, traffic_src = pmc_traffic(fs, args.log2n, args.bursts) if (n_gpus == 1 and not intfmt) else (None, None)
+        traffic, traffic_src = pmc_traffic(args.format, fs, args.bursts, args.mixed_df, args.log2n) if n_gpus == 1 else (None, None)
         result = {
             "metric": "IQ Msamples/s through framer+demod",
             "value": round(value, 1),
@@ -746,6 +797,7 @@ def main():
             del iq
             torch.cuda.empty_cache()
             result["extra_configs"] = extra_configs(args, dev, DEPTH)
+            result["formats"] = format_legs(args, dev, DEPTH)
         print(json.dumps(result), flush=True)
     if n_gpus > 1:
         sync_all()

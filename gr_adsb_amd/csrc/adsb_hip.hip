@@ -230,6 +230,7 @@ struct adsb_ctx {
   // 930 with three; MI355X, tools/r3_variants.sh): 6 KB of padding lifts a workgroup over the 32 KB that five per CU allow
   // and still leaves room for the tail kernels of the previous pass beside it.
   unsigned det_dyn_lds[ADSB_FMT_COUNT] = {0, 6144, 6144, 6144, 6144};
+  unsigned lds_beside[ADSB_FMT_COUNT] = {0, 0, 0, 0, 0};    // LDS a CU has left beside its resident k_detect workgroups
   // integer IQ component -> float32 multiplier per format (adsb_set_format_scale); unused for the float formats
   float scale[ADSB_FMT_COUNT] = {1.0f, 1.0f, 1.0f / 32768.0f, 1.0f / 128.0f, 1.0f / 255.0f};
   FramerState st;       // framer.py:54,57
@@ -311,6 +312,12 @@ void launch_detect(adsb_ctx* c, const DetectArgs& a, int grid) {
   }
 }
 template <int MODE>
+unsigned detect_static_lds() {
+  hipFuncAttributes at;
+  if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_detect<MODE, 0>)) != hipSuccess) { (void)hipGetLastError(); return 32768u; }
+  return (unsigned)at.sharedSizeBytes;
+}
+template <int MODE>
 int detect_occupancy(unsigned dyn) {
   // (the instances of one format differ only in tap addressing: the same resources decide)
   int nb = 0;
@@ -369,6 +376,8 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   // 1.56 ms per 2^30-sample pass); kept out -- k_scan, the first kernel of the chain, is launched with 8 KB of unused
   // dynamic LDS, more than five k_detect workgroups leave free on a CU -- it runs when that k_detect drains.
   // Throughput is the default, ADSB_FLAG_LOW_LATENCY selects the other.
+  // (8 KB: measured.  A padding sized to what k_detect leaves free -- 16 KB for complex64, 25 KB beside the narrow formats'
+  // four workgroups -- keeps the chain out more strictly and was SLOWER on every workload: int16 791 vs 1039 Gsamples/s)
   const unsigned scan_pad = (c->flags & ADSB_FLAG_LOW_LATENCY) ? 0u : 8192u;
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(kThreads), scan_pad, ts, (const int*)a.blk_count,
                      (const long long*)a.blk_lastp, (const unsigned*)a.blk_flags, s.nlists, s.rec_cap,
@@ -709,6 +718,13 @@ int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx
     if ((nb = detect_occupancy<2>(c->det_dyn_lds[2])) > 0) c->bpc[2] = nb;
     if ((nb = detect_occupancy<3>(c->det_dyn_lds[3])) > 0) c->bpc[3] = nb;
     if ((nb = detect_occupancy<4>(c->det_dyn_lds[4])) > 0) c->bpc[4] = nb;
+    const unsigned st[ADSB_FMT_COUNT] = {detect_static_lds<0>(), detect_static_lds<1>(), detect_static_lds<2>(),
+                                         detect_static_lds<3>(), detect_static_lds<4>()};
+    for (int m = 0; m < ADSB_FMT_COUNT; ++m) {
+      const unsigned per = (st[m] + c->det_dyn_lds[m] + 1279u) / 1280u * 1280u;             // LDS allocation granule on gfx950
+      const unsigned used = per * (unsigned)c->bpc[m];
+      c->lds_beside[m] = used < 163840u ? 163840u - used : 0u;
+    }
   }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return -EIO; }
   c->own_stream = true;

@@ -1,51 +1,66 @@
 #!/bin/bash
-# Collect the round's rocprofv3 evidence on the GPU box and leave only small text summaries under
-# gpurun_out/prof/ (gpurun merges <= 64 MiB back).  Run from the repo root:  bash tools/profile_round.sh [rNN]
-# Counters are collected in their own passes with --kernel-trace only (never with sys/hip/hsa traces).
+# The round's rocprofv3 evidence, per BASELINE config and per input format, collected on the GPU box; only small text
+# summaries are left under gpurun_out/prof/ (gpurun merges <= 64 MiB back).   bash tools/profile_round.sh [rNN] [quick]
+# For every workload W:
+#   <R>_<W>_kernel_trace.txt   rocprofv3 --kernel-trace --stats (per-kernel calls / avg / min / max), the bench's own JSON line
+#                              of that (profiled) run, and the clocks / power rocm-smi saw while it ran
+#   <R>_<W>_pmc_hbm.txt        rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE: separate passes, --kernel-trace only
+#   <R>_<W>_bench.json         an UNPROFILED bench line of the same workload on the same box + its clocks line
+# plus the SQ instruction / wait counters for the headline workload and the full default bench line.
+# Counters are never collected together with sys / hip / hsa traces.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 W=/tmp/adsb_prof; rm -rf $W; mkdir -p $W
-cd /tmp
+S="python $ROOT/tools/smi_sampler.py"
 B="python $ROOT/bench.py --no-cpu --no-extra --no-hostfed"
-
-# 1. kernel trace of the default bench (tail kernels on their own stream, 3 passes in flight)
-rocprofv3 --kernel-trace --stats -d $W/kt -o kt -- $B > $W/kt.log 2>&1
-DB=$(find $W/kt -name '*.db' | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --no-extra --no-hostfed   (tail on its own stream, 3 passes in flight)";
-  echo "# profiled runs overlap the streams less and clock lower than unprofiled ones; the bench's JSON line of THIS run is at the bottom";
-  python $ROOT/tools/prof_summary.py "$DB"; echo; grep '"metric"' $W/kt.log | tail -1; } > $OUT/${R}_kernel_trace_stats_bench_default.txt 2>&1
-
-# 2. the same with every kernel on one stream (ADSB_FLAG_SINGLE_STREAM)
-rocprofv3 --kernel-trace --stats -d $W/kt1 -o kt1 -- $B --single-stream > $W/kt1.log 2>&1
-DB=$(find $W/kt1 -name '*.db' | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --no-extra --no-hostfed --single-stream";
-  python $ROOT/tools/prof_summary.py "$DB"; echo; grep '"metric"' $W/kt1.log | tail -1; } > $OUT/${R}_kernel_trace_stats_bench_single_stream.txt 2>&1
-
-# 3. HBM traffic counters, one pass each (2^30 and 2^28 samples per launch)
-for L in 30 28; do
+# name | bench arguments (the headline at the bench's own default size; the others at 2^28 samples like extra_configs)
+WL=(
+ "cfg2_2msps_fc32|"
+ "cfg3_8msps_dense_fc32|--fs 8e6 --bursts 6000 --log2n 28"
+ "cfg4_20msps_fc32|--fs 20e6 --log2n 28"
+ "cfg5_mixed_df_fc32|--mixed-df --log2n 28"
+ "fmt_mag2|--format mag2 --log2n 28"
+ "fmt_sc16|--format sc16 --log2n 28"
+ "fmt_sc8|--format sc8 --log2n 28"
+ "fmt_cu8|--format cu8 --log2n 28"
+)
+cd /tmp
+for w in "${WL[@]}"; do
+  name=${w%%|*}; args=${w#*|}
+  # 1. kernel trace (default pipeline: tail kernels on their own stream, three passes in flight)
+  $S $W/$name.kt.clk -- rocprofv3 --kernel-trace --stats -d $W/kt_$name -o kt -- $B $args --steps 10 --warmup 3 --min-time 0.2 > $W/kt_$name.log 2>&1
+  DB=$(find $W/kt_$name -name '*.db' | head -1)
+  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --no-extra --no-hostfed $args --steps 10 --warmup 3 --min-time 0.2";
+    echo "# (in the default pipeline the tail chain of a pass starts when the NEXT pass's k_detect drains: k_scan's duration is that wait)";
+    python $ROOT/tools/prof_summary.py "$DB"; echo; echo "# the bench's own JSON line of this profiled run (roofline.kernel_ms = HIP events on the compute stream):";
+    grep '"metric"' $W/kt_$name.log | tail -1; echo; echo "# rocm-smi while it ran (samples with the GPU busy):"; cat $W/$name.kt.clk; } > $OUT/${R}_${name}_kernel_trace.txt 2>&1
+  # 2. HBM traffic counters, one pass each
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --kernel-trace -f csv -d $W/pmc_${C}_$L -o p -- $B --log2n $L --steps 4 --warmup 1 --min-time 0 > $W/pmc_${C}_$L.log 2>&1
+    rocprofv3 --pmc $C --kernel-trace -f csv -d $W/pmc_${C}_$name -o p -- $B $args --steps 4 --warmup 1 --min-time 0 > $W/pmc_${C}_$name.log 2>&1
   done
-  { echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python bench.py --log2n $L --steps 4 --warmup 1 --min-time 0 --no-cpu --no-extra --no-hostfed   (KiB per launch)";
-    python $ROOT/tools/pmc_summary.py $(find $W/pmc_FETCH_SIZE_$L -name '*counter_collection.csv' | head -1) \
-                                      $(find $W/pmc_WRITE_SIZE_$L -name '*counter_collection.csv' | head -1); } > $OUT/${R}_pmc_hbm_traffic_log2n$L.txt 2>&1
+  { echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python bench.py --no-cpu --no-extra --no-hostfed $args --steps 4 --warmup 1 --min-time 0   (KiB per launch)";
+    python $ROOT/tools/pmc_summary.py $(find $W/pmc_FETCH_SIZE_$name -name '*counter_collection.csv' | head -1) \
+                                      $(find $W/pmc_WRITE_SIZE_$name -name '*counter_collection.csv' | head -1);
+    echo; grep '"metric"' $W/pmc_FETCH_SIZE_$name.log | tail -1 | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); print('# algorithmic bytes per launch: %d (samples per launch x bytes per sample)' % d['roofline']['algorithmic_bytes_per_launch'])"; } > $OUT/${R}_${name}_pmc_hbm.txt 2>&1
+  # 3. the same workload unprofiled, same box
+  (cd $ROOT && $S $W/$name.plain.clk -- $B $args > $OUT/${R}_${name}_bench.json 2>> $W/bench.err; cat $W/$name.plain.clk >> $OUT/${R}_${name}_bench.json)
+  [ "${2:-}" = quick ] && break
 done
-
-# 4. SQ counters (waits / issue / instruction mix) for the same command
+# 4. SQ counters (waits / issue / instruction mix), headline workload
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -f csv -d $W/sq1 -o p -- $B --steps 4 --warmup 1 --min-time 0 > $W/sq1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace -f csv -d $W/sq2 -o p -- $B --steps 4 --warmup 1 --min-time 0 > $W/sq2.log 2>&1
 python $ROOT/tools/pmc_summary.py $(find $W/sq1 -name '*counter_collection.csv' | head -1) \
                                   $(find $W/sq2 -name '*counter_collection.csv' | head -1) > $OUT/${R}_pmc_sq_counters.txt 2>&1
-
-# 5. unprofiled bench lines on the same box: the full default line, the other signal configs, the integer formats
+# 5. the full default bench line (CPU baselines, bit-match, host-fed per format, extra_configs), unprofiled
 cd $ROOT
-python bench.py > $OUT/${R}_bench_unprofiled.json 2> $W/bench.err
-python bench.py --fs 8e6 --bursts 6000 --no-cpu --no-extra --no-hostfed > $OUT/${R}_bench_8msps_dense.json 2>> $W/bench.err
-python bench.py --fs 20e6 --no-cpu --no-extra --no-hostfed > $OUT/${R}_bench_20msps.json 2>> $W/bench.err
-for f in sc16 sc8 cu8; do python bench.py --format $f --no-cpu > $OUT/${R}_bench_$f.json 2>> $W/bench.err; done
+$S $W/full.clk -- python bench.py > $OUT/${R}_bench_unprofiled.json 2>> $W/bench.err
+cat $W/full.clk >> $OUT/${R}_bench_unprofiled.json
 tail -5 $W/bench.err > $OUT/${R}_bench_stderr_tail.txt
 ls -la $OUT

@@ -28,6 +28,11 @@ __device__ __forceinline__ void adsb_wave_sync() {
 
 __device__ __forceinline__ int adsb_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int adsb_readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// `v`, made to depend on `after` without an instruction: whatever uses the result cannot be scheduled before `after` exists
+__device__ __forceinline__ unsigned adsb_after(unsigned v, float after) {
+  asm volatile("" : "+v"(v) : "v"(after));
+  return v;
+}
 // the value itself, but opaque to the optimiser (per-lane: a vector register)
 __device__ __forceinline__ int adsb_opaque(int v) {
   asm volatile("" : "+v"(v));
@@ -57,6 +62,17 @@ __device__ __forceinline__ unsigned adsb_above4(unsigned acc, float a, float b, 
       : "v"(acc), "s"(thr), "v"(a), "v"(b), "v"(c), "v"(d)
       : "vcc");
   return acc;
+}
+// x*x + y*y with two rounded products and one rounded add: one packed multiply on the register pair the
+// sample was loaded into, one add.  As asm statements because the compiler's own packing of re*re + im*im wants (re0, re1) /
+// (im0, im1) pairs and pays for them with three or four register moves per 16-byte load.
+__device__ __forceinline__ float adsb_mag2(float x, float y) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f a = {x, y}, r;
+  float m;
+  asm("v_pk_mul_f32 %0, %1, %1" : "=v"(r) : "v"(a));
+  asm("v_add_f32 %0, %1, %2" : "=v"(m) : "v"(r.x), "v"(r.y));
+  return m;
 }
 // maximum of three floats with the hardware's own NaN rule (a quiet NaN operand is skipped); as an asm statement so that
 // no canonicalising instruction is spent on operands that come straight from memory

@@ -195,11 +195,17 @@ inline void adsb_wave_sync() {
 
 inline int adsb_uniform(int v) { return v; }
 inline int adsb_opaque(int v) { return v; }
+inline unsigned adsb_after(unsigned v, float) { return v; }
 #define ADSB_LDS
 template <class Q> inline Q adsb_ld_stream(const char* p) { Q q; memcpy(&q, p, sizeof(Q)); return q; }
 inline int adsb_readlane(int v, int lane) { return hipsim_shfl_idx(v, lane); }
 inline unsigned adsb_above4(unsigned acc, float a, float b, float c, float d, float thr) {
   return (acc << 4) | ((a >= thr) ? 8u : 0u) | ((b >= thr) ? 4u : 0u) | ((c >= thr) ? 2u : 0u) | ((d >= thr) ? 1u : 0u);
+}
+inline float adsb_mag2(float x, float y) {
+  volatile float a = x * x, b = y * y;
+  volatile float m = a + b;
+  return m;
 }
 inline float adsb_fmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 inline unsigned adsb_lane_up1(unsigned v, unsigned fill) {

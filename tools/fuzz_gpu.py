@@ -66,7 +66,8 @@ def main():
             sch = []
             while sum(sch) < n:
                 sch.append(int(min(rng.choice([1, 7, 100, 700, 4096, 9000]), n - sum(sch))))
-            fr, dm = blocks.framer(sps * 1e6, thr), blocks.demod(sps * 1e6)
+            fr = blocks.framer(sps * 1e6, thr)
+            dm = blocks.demod(sps * 1e6, framer=fr if rng.random() < 0.5 else None)    # paired: PDUs from the framer's pass
             dm.start_timestamp = 0.0
             tags, msgs = grshim.drive(fr, dm, x, sch)
             o = O.run_stream(x, sps * 1e6, thr, sch)

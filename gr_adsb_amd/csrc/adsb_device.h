@@ -357,9 +357,12 @@ __device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, fl
   const int kt = adsb_uniform((nwin - 1) >> 1);
   unsigned lo = 0u, span = 0u;
   bool single = false;
-  // Eight rounds of four steps.  After 16, 20 and 24 decided bits: does the interval [lo, lo + 2^bit) hold exactly one
-  // key?  Then that key IS the answer -- the usual case for float noise after 16 bits (half the steps); streams
-  // quantised to a few levels (8-bit IQ) hold duplicates around the median and simply run all 32 steps.
+  // Eight rounds of four steps.  After 16, 20 and 24 decided bits: what does the interval [lo, lo + 2^bit) hold?  Exactly
+  // one key: that key IS the answer -- the usual case for float noise after 16 bits (half the steps).  Four or more keys
+  // that are all EQUAL (minimum == maximum of the keys inside): that value is the answer -- the usual case for streams
+  // quantised to a few levels (8-bit IQ), whose median sits in a crowd of duplicates.  Otherwise on with the search.
+  unsigned A = 0u;
+  bool have = false;
   for (int bit = 31; bit >= 0; bit -= 4) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -369,17 +372,26 @@ __device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, fl
     }
     if (bit <= 19 && bit >= 11) {
       const unsigned sp = 1u << (bit - 3);
-      const int inside = adsb_uniform(__popcll(__ballot(k0 - lo < sp)) + __popcll(__ballot(k1 - lo < sp)));
+      const bool in0 = k0 - lo < sp, in1 = k1 - lo < sp;
+      const int inside = adsb_uniform(__popcll(__ballot(in0)) + __popcll(__ballot(in1)));
       if (inside == 1) { single = true; span = sp; break; }
+      if (inside >= 4) {                                      // wave-uniform
+        unsigned mn = in0 ? k0 : 0xFFFFFFFFu, mx = in0 ? k0 : 0u;
+        if (in1) { mn = k1 < mn ? k1 : mn; mx = k1 > mx ? k1 : mx; }
+        mn = adsb_wave_min_u32(mn);
+        mx = adsb_wave_max_u32(mx);
+        if (mn == mx) { A = mn; have = true; break; }
+      }
     }
   }
-  unsigned A = lo;                                           // key of the lower middle
   if (single) {                                              // wave-uniform: fetch the one key inside [lo, lo + span)
     const unsigned long long m0 = __ballot(k0 - lo < span), m1 = __ballot(k1 - lo < span);
     const unsigned a0 = (unsigned)adsb_readlane((int)k0, m0 ? __builtin_ctzll(m0) : 0);
     const unsigned a1 = (unsigned)adsb_readlane((int)k1, m1 ? __builtin_ctzll(m1) : 0);
     A = m0 ? a0 : a1;
+    have = true;
   }
+  if (!have) A = lo;                                         // key of the lower middle
   float med;
   if (nwin == 0) med = __builtin_bit_cast(float, 0xFFC00000u);       // np.median([]) == 0/0: default NaN, sign set
   else if (nanm) med = __builtin_bit_cast(float, 0x7FC00000u);        // a NaN in the window propagates

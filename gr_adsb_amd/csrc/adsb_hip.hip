@@ -107,6 +107,18 @@ __device__ __forceinline__ unsigned adsb_wave_min_u32(unsigned v) {
 #undef ADSB_MIN_STEP
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+// maximum over the 64 lanes (wave-uniform result)
+__device__ __forceinline__ unsigned adsb_wave_max_u32(unsigned v) {
+#define ADSB_MAX_STEP(ctrl, rows)                                                                 \
+  {                                                                                                \
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xF, false);   \
+    v = o > v ? o : v;                                                                             \
+  }
+  ADSB_MAX_STEP(0x111, 0xF) ADSB_MAX_STEP(0x112, 0xF) ADSB_MAX_STEP(0x114, 0xF) ADSB_MAX_STEP(0x118, 0xF)
+  ADSB_MAX_STEP(0x142, 0xA) ADSB_MAX_STEP(0x143, 0xC)
+#undef ADSB_MAX_STEP
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 // workgroup-local (LDS) address space qualifier for pointers that crossed a function call as generic pointers
 #define ADSB_LDS __attribute__((address_space(3)))
 // bit i of x -> bits 2i and 2i+1 (scalar unit; the argument must be wave-uniform)

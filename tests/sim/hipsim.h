@@ -229,6 +229,14 @@ inline unsigned adsb_wave_min_u32(unsigned v) {
   }
   return v;
 }
+inline unsigned adsb_wave_max_u32(unsigned v) {
+  const int lane = hipsim::cur_block()->cur & 63;
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned o = hipsim_shfl_idx(v, lane ^ d);
+    if (o > v) v = o;
+  }
+  return v;
+}
 inline unsigned long long adsb_bitrep32(unsigned x) {
   unsigned long long r = 0;
   for (int i = 0; i < 32; ++i) if ((x >> i) & 1u) r |= 3ull << (2 * i);

@@ -4,6 +4,7 @@
 # For every workload W:
 #   <R>_<W>_kernel_trace.txt   rocprofv3 --kernel-trace --stats (per-kernel calls / avg / min / max), the bench's own JSON line
 #                              of that (profiled) run, and the clocks / power rocm-smi saw while it ran
+#   <R>_<W>_kernel_trace_single_stream.txt   the same on one stream: every kernel alone (compare with roofline.isolated)
 #   <R>_<W>_pmc_hbm.txt        rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE: separate passes, --kernel-trace only
 #   <R>_<W>_bench.json         an UNPROFILED bench line of the same workload on the same box + its clocks line
 # plus the SQ instruction / wait counters for the headline workload and the full default bench line.
@@ -38,6 +39,14 @@ for w in "${WL[@]}"; do
     echo "# (in the default pipeline the tail chain of a pass starts when the NEXT pass's k_detect drains: k_scan's duration is that wait)";
     python $ROOT/tools/prof_summary.py "$DB"; echo; echo "# the bench's own JSON line of this profiled run (roofline.kernel_ms = HIP events on the compute stream):";
     grep '"metric"' $W/kt_$name.log | tail -1; echo; echo "# rocm-smi while it ran (samples with the GPU busy):"; cat $W/$name.kt.clk; } > $OUT/${R}_${name}_kernel_trace.txt 2>&1
+  # 1b. the same with every kernel on ONE stream (ADSB_FLAG_SINGLE_STREAM): k_detect and the tail kernels each alone --
+  #     the figure to hold against `roofline.isolated` of the unprofiled line (the pipelined trace above also times the
+  #     tail kernels that run BESIDE the next k_detect, which the profiler stretches)
+  rocprofv3 --kernel-trace --stats -d $W/kt1_$name -o kt1 -- $B $args --single-stream --steps 10 --warmup 3 --min-time 0.2 > $W/kt1_$name.log 2>&1
+  DB=$(find $W/kt1_$name -name '*.db' | head -1)
+  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --no-extra --no-hostfed $args --single-stream --steps 10 --warmup 3 --min-time 0.2";
+    python $ROOT/tools/prof_summary.py "$DB" | grep -i "kernel \|adsb"; echo; echo "# the bench's own JSON line of this profiled run:";
+    grep '"metric"' $W/kt1_$name.log | tail -1; } > $OUT/${R}_${name}_kernel_trace_single_stream.txt 2>&1
   # 2. HBM traffic counters, one pass each
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C --kernel-trace -f csv -d $W/pmc_${C}_$name -o p -- $B $args --steps 4 --warmup 1 --min-time 0 > $W/pmc_${C}_$name.log 2>&1

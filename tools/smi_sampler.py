@@ -86,10 +86,10 @@ def main():
     th.join(timeout=6)
     with open(out_path, "a") as f:
         line = {"cmd": " ".join(cmd)[-160:], "seconds": round(time.time() - t0, 1), "samples": len(rows)}
-        # only the samples taken while the GPU was busy (power in the upper half of what was seen) say anything about the run
-        if rows and any("power" in r for r in rows):
-            pw = [r.get("power", 0.0) for r in rows]
-            hot = [r for r in rows if r.get("power", 0.0) >= 0.5 * max(pw)]
+        # only the samples taken while the GPU was busy say anything about the run: shader clock within 20 % of the highest seen
+        if rows and any("sclk" in r for r in rows):
+            top = max(r.get("sclk", 0) for r in rows)
+            hot = [r for r in rows if r.get("sclk", 0) >= 0.8 * top]
             line["busy_samples"] = len(hot)
             for key in ("sclk", "mclk", "power"):
                 v = [r[key] for r in hot if key in r]

@@ -318,7 +318,7 @@ def extra_configs(args, dev, depth):
 
 
 def format_legs(args, dev, depth):
-    """The other input formats on the headline signal (BASELINE config 2: 2 Msps, ~1 k DF17 bursts/s) at 2^28 samples:
+    """The other input formats on the headline signal (BASELINE config 2: 2 Msps, ~1 k DF17 bursts/s) at the headline's size:
     float32 |IQ|^2 (the framer's literal input), int16 IQ, int8 IQ, RTL-SDR uint8 IQ -- each with its own roofline record
     (algorithmic bytes = samples x bytes per sample of THAT format) and its own parity check against the C oracle fed
     with the oracle's exact conversion of the same bytes."""
@@ -327,7 +327,7 @@ def format_legs(args, dev, depth):
     from gr_adsb_amd.frontend import FrontEnd
     from oracle import adsb_oracle as O
     from oracle import c_oracle as C
-    log2n = args.extra_log2n
+    log2n = args.log2n
     n, cpu_n = 1 << log2n, 1 << 25
     fs, sps = 2e6, 2
     base = gen_stream_blocks(n, 0, fs, 1000.0, args.seed, dev)

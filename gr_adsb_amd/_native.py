@@ -161,8 +161,14 @@ class Context:
         if rc != 0:
             raise AdsbError(rc, self.lib.adsb_last_error(self._h).decode("utf-8", "replace"))
 
+    def set_threshold_cached(self, thr):
+        """set_threshold, skipped while the value is unchanged (the blocks call this once per work())."""
+        if thr != getattr(self, "_thr_cached", None):
+            self.set_threshold(thr)
+
     def set_threshold(self, thr):
         self._chk(self.lib.adsb_set_threshold(self._h, float(np.float32(thr))))
+        self._thr_cached = thr
 
     def set_stream(self, stream_handle):
         self._chk(self.lib.adsb_set_stream(self._h, ctypes.c_void_p(int(stream_handle))))
@@ -319,11 +325,19 @@ class Context:
         return np.float32(p.value), int(e.value)
 
     def framer_work(self, in0, N, nitems_written):
-        in0 = np.ascontiguousarray(in0, dtype=np.float32)
-        n_out = ctypes.c_int32(0)
-        self._chk(self.lib.adsb_framer_work(self._h, ctypes.c_void_p(in0.ctypes.data), len(in0), int(N), int(nitems_written),
-                                            None, 0, ctypes.byref(n_out)))
-        return self.last_result()
+        if in0.dtype != np.float32 or not in0.flags.c_contiguous:
+            in0 = np.ascontiguousarray(in0, dtype=np.float32)
+        buf = getattr(self, "_tag_buf", None)
+        if buf is None:
+            buf = self._tag_buf = np.zeros(512, dtype=BURST_DTYPE)     # tags of one work() call, filled by the library
+            self._tag_n = ctypes.c_int32(0)
+            self._tag_ptr = ctypes.c_void_p(buf.ctypes.data)
+        rc = self.lib.adsb_framer_work(self._h, ctypes.c_void_p(in0.ctypes.data), len(in0), int(N), int(nitems_written),
+                                       self._tag_ptr, len(buf), ctypes.byref(self._tag_n))
+        if rc == -28:                                                  # -ENOSPC: more tags than the buffer holds
+            return self.last_result()
+        self._chk(rc)
+        return buf[:self._tag_n.value].copy()
 
     def demod_work(self, in0, nitems_read, tag_offsets, want_ratio=False):
         in0 = np.ascontiguousarray(in0, dtype=np.float32)

@@ -136,7 +136,7 @@ class framer(gr.sync_block):
         in0 = input_items[0]
         out0 = output_items[0]
         N = len(out0)
-        self._ctx.set_threshold(self.threshold)
+        self._ctx.set_threshold_cached(self.threshold)
         if self.improved:
             return self._work_improved(in0, out0)
         bursts = self._ctx.framer_work(in0[:N + self.N_hist - 1], N, self.nitems_written(0))

@@ -780,7 +780,7 @@ __device__ __forceinline__ bool chips_match(const float* tp, int half_rt) {
 
 // HALF = samples per chip (sps/2) when it is one of the instantiated rates (2, 4, 8, 20 Msps), else 0 = run-time value.
 template <int MODE, int HALF>
-__global__ void __launch_bounds__(kThreads, kMinWaves) k_detect(DetectArgs a) {
+__device__ __forceinline__ void detect_body(const DetectArgs& a, const int block) {
   __shared__ __attribute__((aligned(16))) float s_xa[kWaves][kBack + kWWin];
   __shared__ __attribute__((aligned(16))) unsigned s_ma[kWaves][kMaskDwords];
   __shared__ __attribute__((aligned(4))) unsigned short s_risea[kWaves][kWTile / 2];
@@ -793,7 +793,7 @@ __global__ void __launch_bounds__(kThreads, kMinWaves) k_detect(DetectArgs a) {
   u16_alias* s_rise = reinterpret_cast<u16_alias*>(s_risea[wave]);
   PendList* pend = &s_penda[wave];
   int n_pend = 0;                                            // wave-uniform: bursts whose last bit samples have not arrived yet
-  const long long unit = (long long)blockIdx.x * kWaves + wave;
+  const long long unit = (long long)block * kWaves + wave;
   const long long c0 = unit * a.chunk;
   long long c1 = c0 + a.chunk;
   if (c1 > a.scan_hi) c1 = a.scan_hi;
@@ -1057,6 +1057,10 @@ __global__ void __launch_bounds__(kThreads, kMinWaves) k_detect(DetectArgs a) {
     a.blk_lastp[unit] = lp >= 0 ? c0 + lp : kNoIndex;
     a.blk_flags[unit] = uflags;
   }
+}
+template <int MODE, int HALF>
+__global__ void __launch_bounds__(kThreads, kMinWaves) k_detect(DetectArgs a) {
+  detect_body<MODE, HALF>(a, (int)blockIdx.x);
 }
 
 // ---- k_longrun: pulses whose run leaves the LDS window (or starts in the zero history) -------------
@@ -1401,6 +1405,35 @@ struct TailArgs {
 template <int MODE>
 __global__ void __launch_bounds__(kThreads) k_tail_small(DetectArgs a, TailArgs t) {
   longrun_body<MODE>(0, 1, a);                                // pulses longer than k_detect's LDS window (usually none)
+  __syncthreads();
+  scan_body(t.blk_count, t.blk_lastp, t.blk_flags, t.nblk, t.rec_cap, t.long_count, t.long_lastp, t.blk_off, t.sum);
+  __syncthreads();
+  gather_body(0, 1, t.cands, t.recs, t.blk_count, t.blk_off, t.nblk, t.rec_cap, t.sorted, t.sorted_recs);
+  __syncthreads();
+  unsigned fmask = 0u, fwant = 0u;
+  if (t.gate_on) {
+    resolve_body(0, 1, t.sorted, t.sum, t.gate, t.gate_long, t.prev_eob);
+    fmask = kKept; fwant = kKept;
+    __syncthreads();
+  }
+  count_body(0, 1, t.sorted, t.sum, fmask, fwant, t.head_n, t.seg_count);
+  __syncthreads();
+  compact_body(0, 1, t.sorted, t.sorted_recs, t.sum, t.seg_count, fmask, fwant, t.head_n, t.out, t.out_cap, t.long_count,
+               t.long_lastp);
+  __syncthreads();
+  if (threadIdx.x == 0) *t.host_sum = *t.sum;
+}
+
+// ---- k_pass_small: a WHOLE small pass -- the one pass over the samples and its tail -- in one workgroup and ONE launch.
+// A GNU Radio work() call of a few thousand samples is four units at most (one workgroup of k_detect) and a handful of
+// centres: its cost is the number of GPU operations, and this is one instead of two.  |IQ|^2 float input only (the
+// framer's input type, adsb_framer_work); the workgroup barrier between the two halves also makes the lists the four
+// wavefronts wrote to global memory visible to each other.
+template <int HALF>
+__global__ void __launch_bounds__(kThreads) k_pass_small(DetectArgs a, TailArgs t) {
+  detect_body<1, HALF>(a, 0);
+  __syncthreads();
+  longrun_body<1>(0, 1, a);
   __syncthreads();
   scan_body(t.blk_count, t.blk_lastp, t.blk_flags, t.nblk, t.rec_cap, t.long_count, t.long_lastp, t.blk_off, t.sum);
   __syncthreads();

@@ -167,6 +167,7 @@ struct Slot {
   hipEvent_t done = nullptr, ev0 = nullptr, ev1 = nullptr, det_done = nullptr, h2d_done = nullptr;
   bool busy = false;
   bool direct = false;           // small pass: k_compact writes the records straight into h_out (no device->host copy)
+  bool fused = false;            // ... and the whole pass is ONE launch (k_pass_small)
   bool is_shard = false;
   bool ev1_valid = false;
   Plan plan{};
@@ -361,6 +362,16 @@ template <int MODE>
 void launch_tail_small(hipStream_t st, const DetectArgs& a, const TailArgs& t) {
   hipLaunchKernelGGL((k_tail_small<MODE>), dim3(1), dim3(kThreads), 0, st, a, t);
 }
+// the whole small pass in one launch (|IQ|^2 float input, one workgroup)
+void launch_pass_small(hipStream_t st, const DetectArgs& a, const TailArgs& t) {
+  switch (a.sps) {
+    case 2: hipLaunchKernelGGL((k_pass_small<1>), dim3(1), dim3(kThreads), 0, st, a, t); break;
+    case 4: hipLaunchKernelGGL((k_pass_small<2>), dim3(1), dim3(kThreads), 0, st, a, t); break;
+    case 8: hipLaunchKernelGGL((k_pass_small<4>), dim3(1), dim3(kThreads), 0, st, a, t); break;
+    case 20: hipLaunchKernelGGL((k_pass_small<10>), dim3(1), dim3(kThreads), 0, st, a, t); break;
+    default: hipLaunchKernelGGL((k_pass_small<0>), dim3(1), dim3(kThreads), 0, st, a, t); break;
+  }
+}
 template <int MODE>
 void launch_confidence(hipStream_t st, int grid, const DetectArgs& a, const Rec* out, const Summary* sum, int cap, float* ratio) {
   hipLaunchKernelGGL((k_confidence<MODE>), dim3(grid), dim3(kThreads), 0, st, a, out, sum, cap, ratio);
@@ -374,7 +385,9 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   hipStream_t ts = c->stream;
   if (s.direct) {
     // a small pass (few lists, at most kDirectRecs centres): the whole tail in one workgroup and one launch, on the
-    // compute stream right behind its k_detect (nothing to overlap: the pass is a few microseconds of GPU time)
+    // compute stream right behind its k_detect (nothing to overlap: the pass is a few microseconds of GPU time) -- or,
+    // when k_detect itself is a single workgroup of |IQ|^2 float input (a GNU Radio work() call), the whole pass in ONE
+    // launch (s.fused: k_detect was not launched)
     TailArgs t;
     t.cands = a.cands; t.recs = a.recs; t.blk_count = a.blk_count; t.blk_lastp = a.blk_lastp; t.blk_flags = a.blk_flags;
     t.blk_off = (int*)s.d_blk_off.p; t.nblk = s.nlists; t.rec_cap = s.rec_cap; t.long_count = a.long_count;
@@ -382,7 +395,8 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
     t.seg_count = (int*)s.d_seg.p; t.sum = &misc->sum; t.host_sum = s.h_sum; t.out = (Rec*)s.h_out; t.out_cap = (int)s.tot;
     t.gate_on = pl.gate ? 1 : 0; t.head_n = pl.head_n; t.gate = 63ll * c->sps;
     t.gate_long = (long long)(pl.long_aware ? 119 : 63) * c->sps; t.prev_eob = pl.prev_eob_stream - pl.origin;
-    ADSB_BY_MODE(pl.mode, launch_tail_small, ts, a, t);
+    if (s.fused) launch_pass_small(ts, a, t);
+    else ADSB_BY_MODE(pl.mode, launch_tail_small, ts, a, t);
     HIPCHK(c, hipEventRecord(s.done, ts));
     return 0;
   }
@@ -495,9 +509,12 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   a.longlist = (LongRise*)s.d_long.p; a.long_count = &misc->long_count; a.long_lastp = &misc->long_lastp;
 
   const bool timing = (c->flags & ADSB_FLAG_TIMING) != 0;
-  if (timing) HIPCHK(c, hipEventRecord(s.ev0, c->stream));
-  ADSB_BY_MODE(pl.mode, launch_detect, c, a, grid);
-  if (timing) HIPCHK(c, hipEventRecord(s.ev1, c->stream));
+  s.fused = s.direct && grid == 1 && pl.mode == ADSB_FMT_MAG2 && !timing;
+  if (!s.fused) {
+    if (timing) HIPCHK(c, hipEventRecord(s.ev0, c->stream));
+    ADSB_BY_MODE(pl.mode, launch_detect, c, a, grid);
+    if (timing) HIPCHK(c, hipEventRecord(s.ev1, c->stream));
+  }
   c->stats.detect_grid = (uint64_t)grid; c->stats.blocks_per_cu = (uint64_t)c->bpc[pl.mode];
   c->stats.calls++;
   s.busy = true;

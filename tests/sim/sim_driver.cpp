@@ -78,6 +78,9 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   a.blk_flags = blk_flags.data(); a.longlist = longlist.data(); a.long_count = &long_count;
   a.long_lastp = &long_lastp;
 
+  // same choice as adsb_hip.hip: enqueue(): a one-workgroup pass over |IQ|^2 floats whose tail is the fused one runs as ONE
+  // kernel, k_pass_small (g_tail_mode 1 = always the kernel chain)
+  const bool one_launch = mode == 1 && grid == 1 && (g_tail_mode == 2 || (g_tail_mode == 0 && tot <= 16384));
   // the instance the library would launch (per format and samples per chip), like adsb_hip.hip: launch_detect()
 #define SIM_DETECT(MODE)                                                                   \
   switch (sps) {                                                                           \
@@ -87,7 +90,7 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     case 20: hipsim::launch(k_detect<MODE, 10>, grid, kThreads, a); break;                 \
     default: hipsim::launch(k_detect<MODE, 0>, grid, kThreads, a); break;                  \
   }
-  switch (mode) {
+  if (!one_launch) switch (mode) {
     case 0: SIM_DETECT(0) break;
     case 1: SIM_DETECT(1) break;
     case 2: SIM_DETECT(2) break;
@@ -106,7 +109,17 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     t.seg_count = seg.data(); t.sum = &sum; t.host_sum = &sum_host; t.out = outv.data(); t.out_cap = (int)tot;
     t.gate_on = gate ? 1 : 0; t.head_n = head_n; t.gate = 63ll * sps; t.gate_long = (long long)(g_long_aware ? 119 : 63) * sps;
     t.prev_eob = prev_eob_stream - origin;
-    SIM_BY_MODE(mode, k_tail_small, 1, kThreads, a, t);
+    if (one_launch) {
+      switch (sps) {
+        case 2: hipsim::launch(k_pass_small<1>, 1, kThreads, a, t); break;
+        case 4: hipsim::launch(k_pass_small<2>, 1, kThreads, a, t); break;
+        case 8: hipsim::launch(k_pass_small<4>, 1, kThreads, a, t); break;
+        case 20: hipsim::launch(k_pass_small<10>, 1, kThreads, a, t); break;
+        default: hipsim::launch(k_pass_small<0>, 1, kThreads, a, t); break;
+      }
+    } else {
+      SIM_BY_MODE(mode, k_tail_small, 1, kThreads, a, t);
+    }
     sum = sum_host;
     if (g_conf_out) SIM_BY_MODE(mode, k_confidence, 2, kThreads, a, (const Rec*)outv.data(), (const Summary*)&sum, (int)tot, g_conf_out);
   } else {

@@ -18,16 +18,16 @@ export TMPDIR=/tmp
 W=/tmp/adsb_prof; rm -rf $W; mkdir -p $W
 S="python $ROOT/tools/smi_sampler.py"
 B="python $ROOT/bench.py --no-cpu --no-extra --no-hostfed"
-# name | bench arguments (the headline at the bench's own default size; the others at 2^28 samples like extra_configs)
+# name | bench arguments (the headline and the other input formats at the bench's own default size, 2^30 samples; configs 3 / 4 / 5 at 2^28 like extra_configs)
 WL=(
  "cfg2_2msps_fc32|"
  "cfg3_8msps_dense_fc32|--fs 8e6 --bursts 6000 --log2n 28"
  "cfg4_20msps_fc32|--fs 20e6 --log2n 28"
  "cfg5_mixed_df_fc32|--mixed-df --log2n 28"
- "fmt_mag2|--format mag2 --log2n 28"
- "fmt_sc16|--format sc16 --log2n 28"
- "fmt_sc8|--format sc8 --log2n 28"
- "fmt_cu8|--format cu8 --log2n 28"
+ "fmt_mag2|--format mag2"
+ "fmt_sc16|--format sc16"
+ "fmt_sc8|--format sc8"
+ "fmt_cu8|--format cu8"
 )
 cd /tmp
 for w in "${WL[@]}"; do

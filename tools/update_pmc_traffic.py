@@ -17,10 +17,10 @@ WORKLOADS = {
     "cfg3_8msps_dense_fc32": ("fc32", 8e6, 6000.0, False, 28),
     "cfg4_20msps_fc32": ("fc32", 20e6, 1000.0, False, 28),
     "cfg5_mixed_df_fc32": ("fc32", 2e6, 1000.0, True, 28),
-    "fmt_mag2": ("mag2", 2e6, 1000.0, False, 28),
-    "fmt_sc16": ("sc16", 2e6, 1000.0, False, 28),
-    "fmt_sc8": ("sc8", 2e6, 1000.0, False, 28),
-    "fmt_cu8": ("cu8", 2e6, 1000.0, False, 28),
+    "fmt_mag2": ("mag2", 2e6, 1000.0, False, 30),
+    "fmt_sc16": ("sc16", 2e6, 1000.0, False, 30),
+    "fmt_sc8": ("sc8", 2e6, 1000.0, False, 30),
+    "fmt_cu8": ("cu8", 2e6, 1000.0, False, 30),
 }
 BYTES = {"fc32": 8, "mag2": 4, "sc16": 4, "sc8": 2, "cu8": 2}
 

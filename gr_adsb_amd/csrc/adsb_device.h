@@ -1226,28 +1226,28 @@ __global__ void __launch_bounds__(kThreads) k_scan(const int* blk_count, const l
   scan_body(blk_count, blk_lastp, blk_flags, nblk, rec_cap, long_count, long_lastp, blk_off, sum);
 }
 
-// ---- k_gather: per-unit lists (centre words + burst records) -> one list each in stream order --------
+// ---- k_gather: per-unit lists of centre words -> one list in stream order; the burst records stay where k_detect wrote
+// them (their list slot travels with the word): round 2 copied them too, 32 MB more of scattered traffic per 2^30-sample
+// pass beside a k_detect that is bound by HBM ------------------------------------------------------------------------
 // (the tail kernels are bodies with the workgroup's index and the grid size as parameters: k_tail_small runs them all
 // in ONE workgroup for small passes)
-__device__ __forceinline__ void gather_body(int bid, int nb, const unsigned long long* cands, const Rec* recs,
-                                            const int* blk_count, const int* blk_off, int nblk, int rec_cap,
-                                            unsigned long long* sorted, Rec* sorted_recs) {
+__device__ __forceinline__ void gather_body(int bid, int nb, const unsigned long long* cands, const int* blk_count,
+                                            const int* blk_off, int nblk, int rec_cap, unsigned long long* sorted,
+                                            unsigned* sorted_src) {
   for (int b = bid; b < nblk; b += nb) {
     int c = blk_count[b];
     if (c > rec_cap) c = rec_cap;
     const int off = blk_off[b];
     const long long src = (long long)b * rec_cap;
-    for (int j = threadIdx.x; j < c; j += kThreads) sorted[off + j] = cands[src + j];
-    // records as 16-byte halves: consecutive threads touch consecutive 16 bytes
-    const RecHalf* rs = reinterpret_cast<const RecHalf*>(recs + src);
-    RecHalf* rd = reinterpret_cast<RecHalf*>(sorted_recs + off);
-    for (int j = threadIdx.x; j < 2 * c; j += kThreads) rd[j] = rs[j];
+    for (int j = threadIdx.x; j < c; j += kThreads) {
+      sorted[off + j] = cands[src + j];
+      sorted_src[off + j] = (unsigned)(src + j);           // where its 32-byte record lies: it is read once, by k_compact
+    }
   }
 }
-__global__ void __launch_bounds__(kThreads) k_gather(const unsigned long long* cands, const Rec* recs, const int* blk_count,
-                                                     const int* blk_off, int nblk, int rec_cap,
-                                                     unsigned long long* sorted, Rec* sorted_recs) {
-  gather_body((int)blockIdx.x, (int)gridDim.x, cands, recs, blk_count, blk_off, nblk, rec_cap, sorted, sorted_recs);
+__global__ void __launch_bounds__(kThreads) k_gather(const unsigned long long* cands, const int* blk_count, const int* blk_off,
+                                                     int nblk, int rec_cap, unsigned long long* sorted, unsigned* sorted_src) {
+  gather_body((int)blockIdx.x, (int)gridDim.x, cands, blk_count, blk_off, nblk, rec_cap, sorted, sorted_src);
 }
 
 // ---- k_resolve: the re-trigger gate (framer.py:121-123,165) as parallel chain walks -----------------
@@ -1331,7 +1331,7 @@ __global__ void __launch_bounds__(kThreads) k_count(const unsigned long long* so
 // k_compact also does what a separate single-workgroup scan kernel used to: every workgroup sums the segment counts
 // in front of its segment itself (a few hundred ints, L2 resident) -- one launch fewer on the tail of every pass.
 // Emits the survivors' burst records (built by k_detect / k_longrun, ordered by k_gather) with kKept / kHead added.
-__device__ __forceinline__ void compact_body(int bid, int nb, const unsigned long long* sorted, const Rec* sorted_recs,
+__device__ __forceinline__ void compact_body(int bid, int nb, const unsigned long long* sorted, const Rec* recs, const unsigned* sorted_src,
                                              Summary* sum, const int* seg_count, unsigned fmask, unsigned fwant, int head_n,
                                              Rec* out, int out_cap, int* long_count, unsigned long long* long_lastp) {
   __shared__ int s_c[kWaves];
@@ -1367,7 +1367,7 @@ __device__ __forceinline__ void compact_body(int bid, int nb, const unsigned lon
     off += lanes_below(m, lane);
     if (seg == 0 && threadIdx.x == 0) sum->n_kept = total;
     if (k && off < out_cap) {
-      Rec r = sorted_recs[i];
+      Rec r = recs[sorted_src[i]];
       unsigned fl = cand_flags(c) & (kKept | kHead);
       if ((unsigned)(r.w[3] >> 48) & kDemod) fl |= parity_flags_of(r.w[2], r.w[3]);
       r.w[3] |= (unsigned long long)fl << 48;
@@ -1377,11 +1377,11 @@ __device__ __forceinline__ void compact_body(int bid, int nb, const unsigned lon
     __syncthreads();
   }
 }
-__global__ void __launch_bounds__(kThreads) k_compact(const unsigned long long* sorted, const Rec* sorted_recs, Summary* sum,
+__global__ void __launch_bounds__(kThreads) k_compact(const unsigned long long* sorted, const Rec* recs, const unsigned* sorted_src, Summary* sum,
                                                       const int* seg_count, unsigned fmask, unsigned fwant, int head_n,
                                                       Rec* out, int out_cap, int* long_count,
                                                       unsigned long long* long_lastp) {
-  compact_body((int)blockIdx.x, (int)gridDim.x, sorted, sorted_recs, sum, seg_count, fmask, fwant, head_n, out, out_cap,
+  compact_body((int)blockIdx.x, (int)gridDim.x, sorted, recs, sorted_src, sum, seg_count, fmask, fwant, head_n, out, out_cap,
                long_count, long_lastp);
 }
 
@@ -1399,7 +1399,7 @@ __global__ void k_publish(const Summary* sum, Summary* host_sum) {
 struct TailArgs {
   const unsigned long long* cands; const Rec* recs; const int* blk_count; const long long* blk_lastp; const unsigned* blk_flags;
   int* blk_off; int nblk, rec_cap; int* long_count; unsigned long long* long_lastp;
-  unsigned long long* sorted; Rec* sorted_recs; int* seg_count; Summary* sum; Summary* host_sum; Rec* out; int out_cap;
+  unsigned long long* sorted; unsigned* sorted_src; int* seg_count; Summary* sum; Summary* host_sum; Rec* out; int out_cap;
   int gate_on, head_n; long long gate, gate_long, prev_eob;
 };
 template <int MODE>
@@ -1408,7 +1408,7 @@ __global__ void __launch_bounds__(kThreads) k_tail_small(DetectArgs a, TailArgs 
   __syncthreads();
   scan_body(t.blk_count, t.blk_lastp, t.blk_flags, t.nblk, t.rec_cap, t.long_count, t.long_lastp, t.blk_off, t.sum);
   __syncthreads();
-  gather_body(0, 1, t.cands, t.recs, t.blk_count, t.blk_off, t.nblk, t.rec_cap, t.sorted, t.sorted_recs);
+  gather_body(0, 1, t.cands, t.blk_count, t.blk_off, t.nblk, t.rec_cap, t.sorted, t.sorted_src);
   __syncthreads();
   unsigned fmask = 0u, fwant = 0u;
   if (t.gate_on) {
@@ -1418,7 +1418,7 @@ __global__ void __launch_bounds__(kThreads) k_tail_small(DetectArgs a, TailArgs 
   }
   count_body(0, 1, t.sorted, t.sum, fmask, fwant, t.head_n, t.seg_count);
   __syncthreads();
-  compact_body(0, 1, t.sorted, t.sorted_recs, t.sum, t.seg_count, fmask, fwant, t.head_n, t.out, t.out_cap, t.long_count,
+  compact_body(0, 1, t.sorted, t.recs, t.sorted_src, t.sum, t.seg_count, fmask, fwant, t.head_n, t.out, t.out_cap, t.long_count,
                t.long_lastp);
   __syncthreads();
   if (threadIdx.x == 0) *t.host_sum = *t.sum;
@@ -1437,7 +1437,7 @@ __global__ void __launch_bounds__(kThreads) k_pass_small(DetectArgs a, TailArgs 
   __syncthreads();
   scan_body(t.blk_count, t.blk_lastp, t.blk_flags, t.nblk, t.rec_cap, t.long_count, t.long_lastp, t.blk_off, t.sum);
   __syncthreads();
-  gather_body(0, 1, t.cands, t.recs, t.blk_count, t.blk_off, t.nblk, t.rec_cap, t.sorted, t.sorted_recs);
+  gather_body(0, 1, t.cands, t.blk_count, t.blk_off, t.nblk, t.rec_cap, t.sorted, t.sorted_src);
   __syncthreads();
   unsigned fmask = 0u, fwant = 0u;
   if (t.gate_on) {
@@ -1447,7 +1447,7 @@ __global__ void __launch_bounds__(kThreads) k_pass_small(DetectArgs a, TailArgs 
   }
   count_body(0, 1, t.sorted, t.sum, fmask, fwant, t.head_n, t.seg_count);
   __syncthreads();
-  compact_body(0, 1, t.sorted, t.sorted_recs, t.sum, t.seg_count, fmask, fwant, t.head_n, t.out, t.out_cap, t.long_count,
+  compact_body(0, 1, t.sorted, t.recs, t.sorted_src, t.sum, t.seg_count, fmask, fwant, t.head_n, t.out, t.out_cap, t.long_count,
                t.long_lastp);
   __syncthreads();
   if (threadIdx.x == 0) *t.host_sum = *t.sum;

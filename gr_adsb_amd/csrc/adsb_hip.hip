@@ -156,7 +156,7 @@ struct Misc {
 // run on the GPU while the records of call i travel over PCIe (adsb_submit_* / adsb_wait), and -- host-fed -- while
 // the samples of call i+2 travel the other way.
 struct Slot {
-  DevBuf d_cands, d_recs, d_sorted, d_sorted_recs, d_out, d_seg, d_blk_count, d_blk_lastp, d_blk_flags, d_blk_off, d_long, d_misc;
+  DevBuf d_cands, d_recs, d_sorted, d_sorted_src, d_out, d_seg, d_blk_count, d_blk_lastp, d_blk_flags, d_blk_off, d_long, d_misc;
   DevBuf d_in;                   // host-fed submissions: this call's samples (adsb_submit_format_host)
   DevBuf d_ratio;                // ADSB_FLAG_CONFIDENCE: [n_kept][112] bit1/bit0 ratios
   Summary* h_sum = nullptr;      // pinned
@@ -391,7 +391,7 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
     TailArgs t;
     t.cands = a.cands; t.recs = a.recs; t.blk_count = a.blk_count; t.blk_lastp = a.blk_lastp; t.blk_flags = a.blk_flags;
     t.blk_off = (int*)s.d_blk_off.p; t.nblk = s.nlists; t.rec_cap = s.rec_cap; t.long_count = a.long_count;
-    t.long_lastp = a.long_lastp; t.sorted = (unsigned long long*)s.d_sorted.p; t.sorted_recs = (Rec*)s.d_sorted_recs.p;
+    t.long_lastp = a.long_lastp; t.sorted = (unsigned long long*)s.d_sorted.p; t.sorted_src = (unsigned*)s.d_sorted_src.p;
     t.seg_count = (int*)s.d_seg.p; t.sum = &misc->sum; t.host_sum = s.h_sum; t.out = (Rec*)s.h_out; t.out_cap = (int)s.tot;
     t.gate_on = pl.gate ? 1 : 0; t.head_n = pl.head_n; t.gate = 63ll * c->sps;
     t.gate_long = (long long)(pl.long_aware ? 119 : 63) * c->sps; t.prev_eob = pl.prev_eob_stream - pl.origin;
@@ -426,9 +426,9 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
                      (const int*)a.long_count, (const unsigned long long*)a.long_lastp, (int*)s.d_blk_off.p, &misc->sum);
   const int gg = s.nlists < 1024 ? s.nlists : 1024;
   unsigned long long* sorted = (unsigned long long*)s.d_sorted.p;
-  Rec* sorted_recs = (Rec*)s.d_sorted_recs.p;
-  hipLaunchKernelGGL(k_gather, dim3(gg), dim3(kThreads), 0, ts, (const unsigned long long*)a.cands, (const Rec*)a.recs,
-                     (const int*)a.blk_count, (const int*)s.d_blk_off.p, s.nlists, s.rec_cap, sorted, sorted_recs);
+  unsigned* sorted_src = (unsigned*)s.d_sorted_src.p;
+  hipLaunchKernelGGL(k_gather, dim3(gg), dim3(kThreads), 0, ts, (const unsigned long long*)a.cands,
+                     (const int*)a.blk_count, (const int*)s.d_blk_off.p, s.nlists, s.rec_cap, sorted, sorted_src);
   const int ag = 512;
   unsigned fmask = 0u, fwant = 0u;
   if (pl.gate) {
@@ -438,7 +438,7 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   }
   hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted,
                      (const Summary*)&misc->sum, fmask, fwant, pl.head_n, (int*)s.d_seg.p);
-  hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted, (const Rec*)sorted_recs,
+  hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted, (const Rec*)a.recs, (const unsigned*)sorted_src,
                      &misc->sum, (const int*)s.d_seg.p, fmask, fwant, pl.head_n, (Rec*)(s.direct ? s.h_out : s.d_out.p), (int)s.tot,
                      a.long_count, a.long_lastp);
   // the summary goes straight into s.h_sum (pinned host memory, device-visible): visible to the host once the `done`
@@ -477,7 +477,8 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   if ((r = ensure(c, s.d_cands, (size_t)s.tot * 8))) return r;
   if ((r = ensure(c, s.d_recs, (size_t)s.tot * sizeof(Rec)))) return r;
   if ((r = ensure(c, s.d_sorted, (size_t)s.tot * 8))) return r;
-  if ((r = ensure(c, s.d_sorted_recs, (size_t)s.tot * sizeof(Rec)))) return r;
+  if (s.tot >= (1ll << 32)) return fail(c, -EINVAL, "input too long for one call (list slots >= 2^32)");
+  if ((r = ensure(c, s.d_sorted_src, (size_t)s.tot * sizeof(unsigned)))) return r;
   // A pass that can deliver only a few records (the GNU Radio work() calls: a few thousand samples) writes them from
   // k_compact straight into the pinned, device-visible result buffer: no device->host copy and no second
   // synchronisation at adsb_wait (the 48-byte summary travels the same way); bulk passes keep the DMA copy.
@@ -801,7 +802,7 @@ void adsb_destroy(adsb_ctx* c) {
   DevBuf* bufs[] = {&c->d_in};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (Slot& sl : c->slot) {
-    DevBuf* sb[] = {&sl.d_cands, &sl.d_recs, &sl.d_sorted, &sl.d_sorted_recs, &sl.d_out, &sl.d_seg, &sl.d_blk_count,
+    DevBuf* sb[] = {&sl.d_cands, &sl.d_recs, &sl.d_sorted, &sl.d_sorted_src, &sl.d_out, &sl.d_seg, &sl.d_blk_count,
                     &sl.d_blk_lastp, &sl.d_blk_flags, &sl.d_blk_off, &sl.d_long, &sl.d_misc, &sl.d_in, &sl.d_ratio};
     for (DevBuf* b : sb) if (b->p) (void)hipFree(b->p);
     if (sl.h_sum) (void)hipHostFree(sl.h_sum);

@@ -60,7 +60,8 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   memcpy(dbuf, data, nby);
 
   std::vector<unsigned long long> cands(tot), sorted(tot);
-  std::vector<Rec> recs(tot), sorted_recs(tot), outv(tot);
+  std::vector<Rec> recs(tot), outv(tot);
+  std::vector<unsigned> sorted_src(tot);
   std::vector<int> blk_count(nlists), blk_off(nlists), seg(tot / kThreads + 2);
   std::vector<long long> blk_lastp(nlists);
   std::vector<unsigned> blk_flags(nlists);
@@ -105,7 +106,7 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     TailArgs t;
     t.cands = cands.data(); t.recs = recs.data(); t.blk_count = blk_count.data(); t.blk_lastp = blk_lastp.data();
     t.blk_flags = blk_flags.data(); t.blk_off = blk_off.data(); t.nblk = nlists; t.rec_cap = rec_cap;
-    t.long_count = &long_count; t.long_lastp = &long_lastp; t.sorted = sorted.data(); t.sorted_recs = sorted_recs.data();
+    t.long_count = &long_count; t.long_lastp = &long_lastp; t.sorted = sorted.data(); t.sorted_src = sorted_src.data();
     t.seg_count = seg.data(); t.sum = &sum; t.host_sum = &sum_host; t.out = outv.data(); t.out_cap = (int)tot;
     t.gate_on = gate ? 1 : 0; t.head_n = head_n; t.gate = 63ll * sps; t.gate_long = (long long)(g_long_aware ? 119 : 63) * sps;
     t.prev_eob = prev_eob_stream - origin;
@@ -127,8 +128,8 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     hipsim::launch(k_scan, 1, kThreads, (const int*)blk_count.data(), (const long long*)blk_lastp.data(),
                    (const unsigned*)blk_flags.data(), nlists, rec_cap, (const int*)&long_count,
                    (const unsigned long long*)&long_lastp, blk_off.data(), &sum);
-    hipsim::launch(k_gather, nlists < 8 ? nlists : 8, kThreads, (const unsigned long long*)cands.data(), (const Rec*)recs.data(),
-                   (const int*)blk_count.data(), (const int*)blk_off.data(), nlists, rec_cap, sorted.data(), sorted_recs.data());
+    hipsim::launch(k_gather, nlists < 8 ? nlists : 8, kThreads, (const unsigned long long*)cands.data(),
+                   (const int*)blk_count.data(), (const int*)blk_off.data(), nlists, rec_cap, sorted.data(), sorted_src.data());
     unsigned fmask = 0u, fwant = 0u;
     if (gate) {
       hipsim::launch(k_resolve, 3, kThreads, sorted.data(), (const Summary*)&sum, (long long)63 * sps,
@@ -137,7 +138,7 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     }
     hipsim::launch(k_count, 3, kThreads, (const unsigned long long*)sorted.data(), (const Summary*)&sum, fmask, fwant,
                    head_n, seg.data());
-    hipsim::launch(k_compact, 3, kThreads, (const unsigned long long*)sorted.data(), (const Rec*)sorted_recs.data(), &sum,
+    hipsim::launch(k_compact, 3, kThreads, (const unsigned long long*)sorted.data(), (const Rec*)recs.data(), (const unsigned*)sorted_src.data(), &sum,
                    (const int*)seg.data(), fmask, fwant, head_n, outv.data(), (int)tot, &long_count, &long_lastp);
     if (g_conf_out) SIM_BY_MODE(mode, k_confidence, 2, kThreads, a, (const Rec*)outv.data(), (const Summary*)&sum, (int)tot, g_conf_out);
   }

@@ -315,3 +315,26 @@ def test_long_aware_gate_matches_its_oracle(fs, bps, mode):
     got0, _ = simlib.sim_canonical(mode, data, fs, 0.01)
     assert_recs_equal(got0, ref, "default mode unchanged")
     assert not (got0["flags"] & 0x2000).any()
+
+
+@pytest.mark.parametrize("sps", [4, 8, 20])
+def test_bits_of_bursts_longer_than_the_window_arrive_later(sps):
+    """At 4 Msps and up a burst is longer than what k_detect's LDS window holds behind a late centre: its bits are taken as
+    the samples arrive (the wavefront's pending list, pend_step), at the end of a wavefront's chunk from global memory
+    (pend_flush).  Dense overlapping bursts over many tiles, tiny grids (chunk ends everywhere) and one unit (none)."""
+    from oracle import c_oracle as C
+    from helpers import assert_recs_equal
+    rng = np.random.default_rng(50 + sps)
+    n = 30000
+    x = rng.exponential(1e-3, n).astype(np.float32)
+    env = M.burst_waveform(M.make_frame(17, rng), sps)
+    for _ in range(40):
+        s = int(rng.integers(0, n - 10))
+        e = min(n, s + len(env))
+        x[s:e] = np.maximum(x[s:e], np.float32(rng.uniform(0.05, 1.0)) * env[:e - s])
+    want = C.canonical(x, sps, np.float32(0.01))
+    assert (want["flags"] & 1).sum() >= 1
+    for gm in (1, 2, 6):
+        got, so = simlib.sim_canonical(1, x, sps * 1e6, 0.01, grid_max=gm)
+        assert so.overflow == 0
+        assert_recs_equal(got, want, "sps %d grid_max %d" % (sps, gm))

@@ -338,3 +338,23 @@ def test_bits_of_bursts_longer_than_the_window_arrive_later(sps):
         got, so = simlib.sim_canonical(1, x, sps * 1e6, 0.01, grid_max=gm)
         assert so.overflow == 0
         assert_recs_equal(got, want, "sps %d grid_max %d" % (sps, gm))
+
+
+@pytest.mark.parametrize("sps", [6, 50, 200])
+def test_sample_rates_without_their_own_instance(sps):
+    """k_detect is instantiated for 2 / 4 / 8 / 20 Msps (preamble taps at immediate offsets); any other even rate runs the
+    run-time-stride instance.  At 50 and 200 samples per microsecond a pulse is longer than a mask unit, a burst spans tens
+    of tiles (pending list across many tiles) and the taps of a late centre leave the LDS window."""
+    rng = np.random.default_rng(3 + sps)
+    n = 120 * sps * 6 + 5000
+    x = rng.exponential(1e-3, n).astype(np.float32)
+    env = M.burst_waveform(M.make_frame(17, rng), sps)
+    for s in (1000, 1000 + 130 * sps, n - len(env) - 300, 2500 + 260 * sps):
+        e = min(n, s + len(env))
+        x[s:e] = np.maximum(x[s:e], np.float32(0.5) * env[:e - s])
+    want = C.canonical(x, sps, np.float32(0.01))
+    assert len(want) >= 3 and (want["flags"] & 1).sum() >= 3
+    for gm in (1, 4):
+        got, so = simlib.sim_canonical(1, x, sps * 1e6, 0.01, grid_max=gm)
+        assert so.overflow == 0
+        assert_recs_equal(got, want, "sps %d grid_max %d" % (sps, gm))

@@ -463,36 +463,46 @@ def host_fed_record(args, fe, iq, depth, formats=("fc32", "sc16", "sc8", "cu8"))
 
 
 def host_fed_all_ranks(args, fe, iq, depth, rank, n_gpus, sync_all, ag_obj):
-    """--gpus N --host-fed: every rank feeds ITS GPU from page-locked host memory through adsb_submit_format_host at the
-    same time (one barrier in front, one behind): the PCIe-inclusive figure of the node, per rank and in total."""
+    """--gpus N (N > 1): every rank feeds ITS GPU from page-locked host memory through adsb_submit_format_host at the
+    same time (one barrier in front, one behind): the PCIe-inclusive figure of the node, per rank and in total.  A rank
+    that fails here reports the error and still takes part in every collective (the headline line must not be lost)."""
     import torch
     from gr_adsb_amd import _native
     chunk = min(iq.shape[0], 1 << args.hostfed_log2n)
-    pinned = [torch.empty((chunk, 2), dtype=torch.float32).pin_memory() for _ in range(3)]
-    for k, p_ in enumerate(pinned):
-        p_.copy_(iq[:chunk])
-    views = [p_.numpy().view(np.complex64).reshape(-1) for p_ in pinned]
-    reps = 12
-    for k in range(2):
-        fe.ctx.wait(fe.ctx.submit_format_host(_native.FMT_FC32, views[k]), fetch=False)
+    reps, err, own, views = 12, None, float("nan"), None
+    try:
+        pinned = [torch.empty((chunk, 2), dtype=torch.float32).pin_memory() for _ in range(3)]
+        for p_ in pinned:
+            p_.copy_(iq[:chunk])
+        views = [p_.numpy().view(np.complex64).reshape(-1) for p_ in pinned]
+        for k in range(2):
+            fe.ctx.wait(fe.ctx.submit_format_host(_native.FMT_FC32, views[k]), fetch=False)
+    except Exception as e:                                       # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
     sync_all()
     t0 = time.perf_counter()
-    pend = []
-    for k in range(reps):
-        pend.append(fe.ctx.submit_format_host(_native.FMT_FC32, views[k % 3]))
-        if len(pend) == depth:
-            fe.ctx.wait(pend.pop(0), fetch=False)
-    while pend:
-        fe.ctx.wait(pend.pop(0), fetch=False)
-    own = time.perf_counter() - t0
+    if err is None:
+        try:
+            pend = []
+            for k in range(reps):
+                pend.append(fe.ctx.submit_format_host(_native.FMT_FC32, views[k % 3]))
+                if len(pend) == depth:
+                    fe.ctx.wait(pend.pop(0), fetch=False)
+            while pend:
+                fe.ctx.wait(pend.pop(0), fetch=False)
+            own = time.perf_counter() - t0
+        except Exception as e:                                   # noqa: BLE001
+            err = "%s: %s" % (type(e).__name__, e)
     sync_all()
     wall = time.perf_counter() - t0
-    per = ag_obj({"rank": rank, "msamples_per_s": round(reps * chunk / own / 1e6, 1), "gbytes_per_s": round(reps * chunk * 8 / own / 1e9, 2)})
+    per = ag_obj({"rank": rank, "msamples_per_s": None if err else round(reps * chunk / own / 1e6, 1),
+                  "gbytes_per_s": None if err else round(reps * chunk * 8 / own / 1e9, 2), "error": err})
     walls = ag_obj(wall)
+    ok = all(r["error"] is None for r in per)
     return {"entry_point": "adsb_submit_format_host (complex64, page-locked source), every rank at once", "chunk_samples": chunk,
             "chunks_per_rank": reps, "per_rank": per,
-            "total": {"value": round(n_gpus * reps * chunk / max(walls) / 1e6, 1), "unit": "Msamples/s",
-                      "gbytes_per_s": round(n_gpus * reps * chunk * 8 / max(walls) / 1e9, 2)}}
+            "total": {"value": round(n_gpus * reps * chunk / max(walls) / 1e6, 1) if ok else None, "unit": "Msamples/s",
+                      "gbytes_per_s": round(n_gpus * reps * chunk * 8 / max(walls) / 1e9, 2) if ok else None}}
 
 
 def main():
@@ -515,8 +525,9 @@ def main():
     ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--extra-min-time", type=float, default=0.25)
     ap.add_argument("--hostfed-log2n", type=int, default=26)
-    ap.add_argument("--host-fed", action="store_true",
-                    help="with --gpus N > 1: also measure the PCIe-inclusive rate, every rank feeding its GPU from page-locked host memory")
+    ap.add_argument("--host-fed", action="store_true", help="(kept for compatibility: with --gpus N > 1 the PCIe-inclusive leg runs by default)")
+    ap.add_argument("--no-host-fed-multi", action="store_true",
+                    help="with --gpus N > 1: skip the PCIe-inclusive leg (every rank feeding its GPU from page-locked host memory)")
     ap.add_argument("--mixed-df", action="store_true",
                     help="BASELINE config 5's signal as the main workload: DF mix of docs/DF_histogram.txt, SNR 3-25 dB over noise 2e-3")
     ap.add_argument("--depth", type=int, default=0, help="passes in flight (default: the library's ADSB_MAX_IN_FLIGHT)")
@@ -707,7 +718,7 @@ def main():
                 "ranks share a GPU (set ADSB_BENCH_ONE_GPU=1 if that is intended)"
         seam = seam_check(args, fe, dev, rank, n_gpus, sps, n_own, stream_len, last_kept[0], ag_obj)
     hf_multi = None
-    if n_gpus > 1 and args.host_fed:
+    if n_gpus > 1 and not args.no_host_fed_multi:
         hf_multi = host_fed_all_ranks(args, fe, iq, DEPTH, rank, n_gpus, sync_all, ag_obj)
 
     result = None

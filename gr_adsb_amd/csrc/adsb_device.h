@@ -347,7 +347,7 @@ __device__ __forceinline__ BurstFetch<MODE> burst_issue(const DetectArgs& a, uns
 // stores the 32-byte record.
 // np.median of the noise window held by a wavefront (framer.py:156-159): lane l has window samples l and l + 64 (v0, v1;
 // valid iff val0, val1; nwin = window length).  Wave-uniform result.
-__device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, float v0, float v1) {
+__device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, float v0, float v1, unsigned& hint) {
   const unsigned long long nanm = __ballot((val0 && v0 != v0) || (val1 && v1 != v1));
   const unsigned k0 = val0 ? f32_key(v0) : 0xFFFFFFFFu;      // lanes outside the window sort last
   const unsigned k1 = val1 ? f32_key(v1) : 0xFFFFFFFFu;
@@ -363,12 +363,38 @@ __device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, fl
   // quantised to a few levels (8-bit IQ), whose median sits in a crowd of duplicates.  Otherwise on with the search.
   unsigned A = 0u;
   bool have = false;
-  for (int bit = 31; bit >= 0; bit -= 4) {
+  auto below = [&](unsigned T) -> int { return adsb_uniform(__popcll(__ballot(k0 < T)) + __popcll(__ballot(k1 < T))); };
+  // The key of the previous burst of this wavefront (`hint`) as a first guess: the noise floor is the same a few hundred
+  // samples on, so the new key almost always lies within 2^23 key units (half to all of its own value) of the old
+  // one.  Two counts PROVE on which side and within that distance it lies (nothing is assumed: a guess that fails
+  // costs its two counts and the search starts from the full range), and replace the first nine steps.
+  bool bracket = false;
+  const unsigned h = (unsigned)adsb_uniform((int)hint);
+  if (h >= 0x00800000u && h < 0xFF000000u) {                 // wave-uniform; h +- 2^23 cannot wrap
+    const bool up = below(h) <= kt;                            // the key is >= h
+    const unsigned T2 = up ? h + 0x00800000u : h - 0x00800000u;
+    const bool c2 = below(T2) <= kt;                           // the key is >= T2
+    bracket = up ? !c2 : c2;
+    if (bracket) lo = up ? h : T2;                             // the key lies in [lo, lo + 2^23)
+  }
+  if (bracket) {
+#pragma unroll
+    for (int b = 22; b >= 20; --b) {
+      const unsigned T = lo + (1u << b);
+      if (below(T) <= kt) lo = T;
+    }
+  } else {
+#pragma unroll
+    for (int b = 31; b >= 20; --b) {
+      const unsigned T = lo | (1u << b);
+      if (below(T) <= kt) lo = T;
+    }
+  }
+  for (int bit = 19; bit >= 0; bit -= 4) {                   // the key lies in [lo, lo + 2^(bit+1)); lo need not be aligned
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const unsigned T = lo | (1u << (bit - j));
-      const int c = adsb_uniform(__popcll(__ballot(k0 < T)) + __popcll(__ballot(k1 < T)));
-      if (c <= kt) lo = T;
+      const unsigned T = lo + (1u << (bit - j));
+      if (below(T) <= kt) lo = T;
     }
     if (bit <= 19 && bit >= 11) {
       const unsigned sp = 1u << (bit - 3);
@@ -392,6 +418,7 @@ __device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, fl
     have = true;
   }
   if (!have) A = lo;                                         // key of the lower middle
+  hint = A;
   float med;
   if (nwin == 0) med = __builtin_bit_cast(float, 0xFFC00000u);       // np.median([]) == 0/0: default NaN, sign set
   else if (nanm) med = __builtin_bit_cast(float, 0x7FC00000u);        // a NaN in the window propagates
@@ -432,7 +459,8 @@ __device__ __forceinline__ void rec_store_bits(Rec* out, unsigned long long ma, 
 __device__ __forceinline__ void burst_reduce(long long offset, int nwin, bool val0, bool val1, float peak, float v0,
                                              float v1, bool dem, float x1, float x0, float y1, float y0, unsigned xflags,
                                              Rec* out, int lane) {
-  const float med = noise_median(nwin, val0, val1, v0, v1);
+  unsigned no_hint = 0u;
+  const float med = noise_median(nwin, val0, val1, v0, v1, no_hint);
   const bool bitA = dem && x1 > x0, bitB = dem && lane < 48 && y1 > y0;                     // demod.py:95
   const unsigned long long ma = __ballot(bitA), mb = __ballot(bitB);
   rec_store_head(out, offset, peak, med, lane);
@@ -545,7 +573,8 @@ __device__ __forceinline__ void slice_window(const float* s_x, int p, int sps, i
 
 template <int MODE>
 __device__ __forceinline__ void burst_from_window(WinArgs a, const float* s_x, long long t0, int p, unsigned xflags,
-                                                  Rec* out, int slot, int lane, PendList* pend, int* n_pend) {
+                                                  Rec* out, int slot, int lane, PendList* pend, int* n_pend,
+                                                  unsigned& med_hint) {
   const int sps = a.sps, half = sps >> 1;
   const long long P = t0 + p;
   long long wlo = P - kNoise;                                // framer.py:156: in0[max(0, pulse_idx-100) : pulse_idx]
@@ -557,7 +586,7 @@ __device__ __forceinline__ void burst_from_window(WinArgs a, const float* s_x, l
   const float v1 = val1 ? s_x[wl + lane + 64] : 0.0f;
   const float peak = s_x[p];
   const bool dem = P + 119ll * sps + half < a.dem_hi;        // demod.py:76,82 (sps even)
-  const float med = noise_median(nwin, val0, val1, v0, v1);
+  const float med = noise_median(nwin, val0, val1, v0, v1, med_hint);
   rec_store_head(out, a.origin + P, peak, med, lane);
   const unsigned flags = (dem ? kDemod : 0u) | xflags;
   unsigned long long ma = 0ull, mb = 0ull;
@@ -801,6 +830,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
   int nrec = 0;                                              // wave-uniform running count of this unit's list
   unsigned uflags = 0u;
   int lp = -1;                                               // per lane: largest paired pulse centre so far, relative to c0
+  unsigned med_hint = 0u;                                    // wave-uniform: median key of this wavefront's previous burst
   int pred = adsb_uniform(above_at<MODE>(a, c0 - 1) ? 1 : 0);
   unsigned long long* my_cands = a.cands + unit * a.rec_cap;
   Rec* my_recs = a.recs + unit * a.rec_cap;
@@ -985,7 +1015,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
             const bool lh = (e & kHitLongHint) != 0;
             if (lane == 0) my_cands[slot2] = cand_make(t0 + (long long)v, lh ? kLongHint : 0u);
             burst_from_window<MODE>(WinArgs{a.data, a.n, a.in0_base, a.dem_hi, a.origin, a.scale, a.sps}, s_x, t0, v,
-                                    lh ? kRecLongHint : 0u, my_recs + slot2, slot2, lane, pend, &n_pend);
+                                    lh ? kRecLongHint : 0u, my_recs + slot2, slot2, lane, pend, &n_pend, med_hint);
           }
         }
         nrec += nm;

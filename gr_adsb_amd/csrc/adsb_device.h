@@ -40,6 +40,8 @@ constexpr int kWTile = 1024;             // samples a wavefront owns per tile it
 constexpr int kFwd = 256;                // forward halo kept in LDS behind every tile
 constexpr int kBack = 128;               // back halo kept in LDS in front of every tile: the <=100-sample noise window (framer.py:156)
 constexpr int kWWin = kWTile + kFwd;
+constexpr int kMaxCentre = (kWTile - 1 + kWWin - 1) / 2;   // largest centre relative to its tile: rise in the tile, fall inside the window
+template <bool B> struct BoolC { static constexpr bool value = B; };
 constexpr int kWWords = kWWin / 64;      // 20
 constexpr int kWOwn = kWTile / 64;       // 16: word owners are lanes 0..15
 constexpr int kHeadWords = kFwd / 64;    // 4
@@ -571,21 +573,27 @@ __device__ __forceinline__ void slice_window(const float* s_x, int p, int sps, i
   *mb = __ballot(tb && y1 > y0);
 }
 
-template <int MODE>
+// EASY (wave-uniform, known per tile): the whole 100-sample noise window of every centre of the tile lies inside the
+// framer's input and every burst that starts in the tile ends inside the demod's -- the usual tile; nothing is clipped.
+template <int MODE, bool EASY>
 __device__ __forceinline__ void burst_from_window(WinArgs a, const float* s_x, long long t0, int p, unsigned xflags,
                                                   Rec* out, int slot, int lane, PendList* pend, int* n_pend,
                                                   unsigned& med_hint) {
   const int sps = a.sps, half = sps >> 1;
   const long long P = t0 + p;
-  long long wlo = P - kNoise;                                // framer.py:156: in0[max(0, pulse_idx-100) : pulse_idx]
-  if (wlo < a.in0_base) wlo = a.in0_base;
-  const int nwin = (int)(P - wlo);
-  const int wl = (int)(wlo - t0);                            // >= p - 100 >= -kBack
-  const bool val0 = lane < nwin, val1 = lane + 64 < nwin;
+  int nwin = kNoise, wl = p - kNoise;
+  bool dem = true;
+  if constexpr (!EASY) {
+    long long wlo = P - kNoise;                              // framer.py:156: in0[max(0, pulse_idx-100) : pulse_idx]
+    if (wlo < a.in0_base) wlo = a.in0_base;
+    nwin = (int)(P - wlo);
+    wl = (int)(wlo - t0);                                    // >= p - 100 >= -kBack
+    dem = P + 119ll * sps + half < a.dem_hi;                 // demod.py:76,82 (sps even)
+  }
+  const bool val0 = EASY || lane < nwin, val1 = lane + 64 < nwin;
   const float v0 = val0 ? s_x[wl + lane] : 0.0f;
   const float v1 = val1 ? s_x[wl + lane + 64] : 0.0f;
   const float peak = s_x[p];
-  const bool dem = P + 119ll * sps + half < a.dem_hi;        // demod.py:76,82 (sps even)
   const float med = noise_median(nwin, val0, val1, v0, v1, med_hint);
   rec_store_head(out, a.origin + P, peak, med, lane);
   const unsigned flags = (dem ? kDemod : 0u) | xflags;
@@ -855,7 +863,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
   //   it_i0 <= it < it_i1 : "interior": the whole tile is owned ([scan_lo, scan_hi)) and the window ends in front of
   //                  fall_hi -> no per-lane 64-bit ownership / end-of-call arithmetic
   constexpr int BPS = mode_bytes(MODE);
-  int ntile = 0, it_re = 0, it_i0 = 0, it_i1 = 0, it_rag = 0;
+  int ntile = 0, it_re = 0, it_i0 = 0, it_i1 = 0, it_rag = 0, it_e0 = 0, it_e1 = 0;
   if (c0 < c1) {
     auto tiles_below = [](long long x) -> long long {          // number of it >= 0 with it*kWTile < x
       return x <= 0 ? 0 : (x + kWTile - 1) / kWTile;
@@ -876,9 +884,17 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
     if (i1f < i1) i1 = i1f;
     it_i0 = clampi(i0, nt);
     it_i1 = clampi(i1, nt);
+    // "easy" tiles (burst_from_window<.., EASY>): interior, c0 + it*T - kNoise >= in0_base, and the latest centre a tile
+    // can hold (kMaxCentre) still has its last bit sample in front of dem_hi
+    long long e0 = tiles_below(a.in0_base + kNoise - c0);
+    long long e1 = tiles_below(a.dem_hi - c0 - kMaxCentre - 119ll * a.sps - (a.sps >> 1));
+    if (e0 < i0) e0 = i0;
+    if (e1 > i1) e1 = i1;
+    it_e0 = clampi(e0, nt);
+    it_e1 = clampi(e1, nt);
   }
   ntile = adsb_uniform(ntile); it_re = adsb_uniform(it_re); it_i0 = adsb_uniform(it_i0); it_i1 = adsb_uniform(it_i1);
-  it_rag = adsb_uniform(it_rag);
+  it_rag = adsb_uniform(it_rag); it_e0 = adsb_uniform(it_e0); it_e1 = adsb_uniform(it_e1);
 
   if (ntile > 0) {
     // head of the window and back halo of the first tile (later tiles inherit both): once per unit and launch
@@ -887,6 +903,102 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
     s_m16[lane & (kHeadUnits - 1)] = (unsigned short)unit_mask(s_x + kUnit * (lane & (kHeadUnits - 1)), thr);
   }
   bool prev_active = true;                                   // the head units were computed exactly
+
+  // -- B.2 one lane per rise: fall, centre, 16-chip test (framer.py:113,137-147); hits are compacted in order over the
+  //    rise list in place (a hit's slot never lies beyond its rise's).  Then C: the tile's hits in stream order.
+  auto rises_to_records = [&](auto easy_c, const int it, const long long t0, const int nr, const int lane) {
+    constexpr bool EASY = decltype(easy_c)::value;
+    const bool interior = EASY || (it >= it_i0 && it < it_i1);
+    int nm = 0;
+    bool hflag = false;
+    const int trel = it * kWTile;
+    for (int base = 0; base < nr; base += 64) {
+      const int i = base + lane;
+      unsigned res = 0u;
+      if (i < nr) {
+        const int r = (int)s_rise[i];
+        // the first sub-threshold sample after r: 32 mask bits from r on (two aligned words), else word by word
+        const int d = r >> 5, sh = r & 31;
+        const unsigned long long two = ((unsigned long long)s_m32[d + 1] << 32) | s_m32[d];
+        const unsigned inv = ~(unsigned)(two >> sh);      // bit 0 (the rise itself) is clear
+        int f = -1;
+        if (inv) {
+          f = r + __builtin_ctz(inv);
+        } else {
+          int wd = d + 1;
+          unsigned cur = ~s_m32[wd] & (~0u << sh);
+          while (cur == 0u && ++wd < kMaskDwords) cur = ~s_m32[wd];
+          if (wd < kMaskDwords && cur) f = wd * 32 + __builtin_ctz(cur);
+        }
+        if (f < 0) {
+          if (EASY || interior || t0 + kWWin < a.fall_hi) res = kHitValid | kHitLongPulse | (unsigned)r;    // k_longrun
+          else if (!a.end_is_call_end) hflag = true;
+        } else if (EASY || interior || t0 + f < a.fall_hi) {
+          const int p = (r + f) >> 1;                    // framer.py:113
+          lp = imax(lp, trel + p);                        // (centres increase along the stream)
+          bool match = true;
+          // all 16 taps inside the LDS window (one LDS round trip): always, at the instantiated rates up to 8 Msps
+          if ((HALF >= 1 && kMaxCentre + 15 * HALF < kWWin) || p + 15 * half < kWWin) {
+            match = chips_match<HALF>(s_x + p, half);
+          } else {                                       // rare: taps past the window come from global memory
+            const float hp = __fmul_rn(s_x[p], 0.5f);
+            unsigned chips = 0;
+#pragma unroll 1
+            for (int k = 0; k < 16; ++k) {
+              const int idx = p + k * half;
+              const float v = (idx < kWWin) ? s_x[idx] : xg<MODE>(a.data, a.n, t0 + idx, a.scale);
+              chips |= (v > hp ? 1u : 0u) << k;
+            }
+            match = chips == kTemplate;
+          }
+          if (match) {
+            res = kHitValid | (unsigned)p;
+            if (a.long_aware) {                          // first data bit (demod.py:87-95, k = 0): DF >= 16 = long reply
+              const int i1 = p + 16 * half, i0 = i1 + half;
+              const float v1 = (i1 < kWWin) ? s_x[i1] : xg<MODE>(a.data, a.n, t0 + i1, a.scale);
+              const float v0 = (i0 < kWWin) ? s_x[i0] : xg<MODE>(a.data, a.n, t0 + i0, a.scale);
+              if (v1 > v0) res |= kHitLongHint;
+            }
+          }
+        } else if (!a.end_is_call_end) {
+          hflag = true;
+        }
+      }
+      const unsigned long long mb = __ballot(res != 0u);
+      if (mb) {                                          // wave-uniform
+        if (res) s_rise[nm + lanes_below(mb, lane)] = (unsigned short)res;
+        nm += __popcll(mb);
+      }
+    }
+    if constexpr (!EASY) {
+      if (!interior && __ballot(hflag)) uflags |= 4u;
+    }
+    adsb_wave_sync();
+
+    // -- C: this tile's hits, in stream order: the list word and, built by the whole wavefront from the LDS
+    //    window while it still holds the burst's samples, the burst record (wave-uniform loop: a tile rarely has
+    //    more than one or two hits)
+    for (int m = 0; m < nm; ++m) {
+      const int slot2 = nrec + m;
+      if (slot2 >= a.rec_cap) break;                     // overflow: reported through the count, call is re-run
+      const unsigned e = (unsigned)adsb_uniform((int)s_rise[m]);
+      const int v = (int)(e & 0x7FFu);
+      if (e & kHitLongPulse) {
+        if (lane == 0) {
+          const long long rg = t0 + v;
+          my_cands[slot2] = cand_make(rg, kPending | kNoMatch);
+          const int li = atomicAdd(a.long_count, 1);
+          if (li < a.long_cap) { LongRise le; le.rise = rg; le.blk = (int)unit; le.slot = slot2; a.longlist[li] = le; }
+        }
+      } else {
+        const bool lh = (e & kHitLongHint) != 0;
+        if (lane == 0) my_cands[slot2] = cand_make(t0 + (long long)v, lh ? kLongHint : 0u);
+        burst_from_window<MODE, EASY>(WinArgs{a.data, a.n, a.in0_base, a.dem_hi, a.origin, a.scale, a.sps}, s_x, t0, v,
+                                      lh ? kRecLongHint : 0u, my_recs + slot2, slot2, lane, pend, &n_pend, med_hint);
+      }
+    }
+    nrec += nm;
+  };
 
   // Everything a tile needs once its body is in the window (floats at s_x[kFwd ..)): mask units, pending bursts, rises,
   // hits, records, the slide.  One body of code, used by the streaming loop and by the loop for tiny inputs below.
@@ -931,94 +1043,12 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
         }
         adsb_wave_sync();
 
-        // -- B.2 one lane per rise: fall, centre, 16-chip test (framer.py:113,137-147); hits are compacted in order
-        //    over the rise list in place (a hit's slot never lies beyond its rise's)
-        int nm = 0;
-        bool hflag = false;
-        const int trel = it * kWTile;
-        for (int base = 0; base < nr; base += 64) {
-          const int i = base + lane;
-          unsigned res = 0u;
-          if (i < nr) {
-            const int r = (int)s_rise[i];
-            // the first sub-threshold sample after r: 32 mask bits from r on (two aligned words), else word by word
-            const int d = r >> 5, sh = r & 31;
-            const unsigned long long two = ((unsigned long long)s_m32[d + 1] << 32) | s_m32[d];
-            const unsigned inv = ~(unsigned)(two >> sh);      // bit 0 (the rise itself) is clear
-            int f = -1;
-            if (inv) {
-              f = r + __builtin_ctz(inv);
-            } else {
-              int wd = d + 1;
-              unsigned cur = ~s_m32[wd] & (~0u << sh);
-              while (cur == 0u && ++wd < kMaskDwords) cur = ~s_m32[wd];
-              if (wd < kMaskDwords && cur) f = wd * 32 + __builtin_ctz(cur);
-            }
-            if (f < 0) {
-              if (interior || t0 + kWWin < a.fall_hi) res = kHitValid | kHitLongPulse | (unsigned)r;    // k_longrun
-              else if (!a.end_is_call_end) hflag = true;
-            } else if (interior || t0 + f < a.fall_hi) {
-              const int p = (r + f) >> 1;                    // framer.py:113
-              lp = imax(lp, trel + p);                        // (centres increase along the stream)
-              bool match = true;
-              if (p + 15 * half < kWWin) {                   // all 16 taps inside the LDS window: one LDS round trip
-                match = chips_match<HALF>(s_x + p, half);
-              } else {                                       // rare: taps past the window come from global memory
-                const float hp = __fmul_rn(s_x[p], 0.5f);
-                unsigned chips = 0;
-#pragma unroll 1
-                for (int k = 0; k < 16; ++k) {
-                  const int idx = p + k * half;
-                  const float v = (idx < kWWin) ? s_x[idx] : xg<MODE>(a.data, a.n, t0 + idx, a.scale);
-                  chips |= (v > hp ? 1u : 0u) << k;
-                }
-                match = chips == kTemplate;
-              }
-              if (match) {
-                res = kHitValid | (unsigned)p;
-                if (a.long_aware) {                          // first data bit (demod.py:87-95, k = 0): DF >= 16 = long reply
-                  const int i1 = p + 16 * half, i0 = i1 + half;
-                  const float v1 = (i1 < kWWin) ? s_x[i1] : xg<MODE>(a.data, a.n, t0 + i1, a.scale);
-                  const float v0 = (i0 < kWWin) ? s_x[i0] : xg<MODE>(a.data, a.n, t0 + i0, a.scale);
-                  if (v1 > v0) res |= kHitLongHint;
-                }
-              }
-            } else if (!a.end_is_call_end) {
-              hflag = true;
-            }
-          }
-          const unsigned long long mb = __ballot(res != 0u);
-          if (mb) {                                          // wave-uniform
-            if (res) s_rise[nm + lanes_below(mb, lane)] = (unsigned short)res;
-            nm += __popcll(mb);
-          }
-        }
-        if (!interior && __ballot(hflag)) uflags |= 4u;
-        adsb_wave_sync();
-
-        // -- C: this tile's hits, in stream order: the list word and, built by the whole wavefront from the LDS
-        //    window while it still holds the burst's samples, the burst record (wave-uniform loop: a tile rarely has
-        //    more than one or two hits)
-        for (int m = 0; m < nm; ++m) {
-          const int slot2 = nrec + m;
-          if (slot2 >= a.rec_cap) break;                     // overflow: reported through the count, call is re-run
-          const unsigned e = (unsigned)adsb_uniform((int)s_rise[m]);
-          const int v = (int)(e & 0x7FFu);
-          if (e & kHitLongPulse) {
-            if (lane == 0) {
-              const long long rg = t0 + v;
-              my_cands[slot2] = cand_make(rg, kPending | kNoMatch);
-              const int li = atomicAdd(a.long_count, 1);
-              if (li < a.long_cap) { LongRise le; le.rise = rg; le.blk = (int)unit; le.slot = slot2; a.longlist[li] = le; }
-            }
-          } else {
-            const bool lh = (e & kHitLongHint) != 0;
-            if (lane == 0) my_cands[slot2] = cand_make(t0 + (long long)v, lh ? kLongHint : 0u);
-            burst_from_window<MODE>(WinArgs{a.data, a.n, a.in0_base, a.dem_hi, a.origin, a.scale, a.sps}, s_x, t0, v,
-                                    lh ? kRecLongHint : 0u, my_recs + slot2, slot2, lane, pend, &n_pend, med_hint);
-          }
-        }
-        nrec += nm;
+        // -- B.2 + C for this tile's rise list, in two instances: EASY (wave-uniform; the usual tile) = the tile is
+        //    interior, every centre's noise window lies inside the framer's input and every burst that starts here ends
+        //    inside the demod's -- no per-lane ownership / end-of-call arithmetic, no clipping; else the general code
+        const bool easy = it >= it_e0 && it < it_e1;
+        if (easy) rises_to_records(BoolC<true>{}, it, t0, nr, lane);
+        else rises_to_records(BoolC<false>{}, it, t0, nr, lane);
       }
     }
 

@@ -370,29 +370,30 @@ __device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, fl
   // samples on, so the new key almost always lies within 2^23 key units (half to all of its own value) of the old
   // one.  Two counts PROVE on which side and within that distance it lies (nothing is assumed: a guess that fails
   // costs its two counts and the search starts from the full range), and replace the first nine steps.
-  bool bracket = false;
   const unsigned h = (unsigned)adsb_uniform((int)hint);
+  bool full = true;
   if (h >= 0x00800000u && h < 0xFF000000u) {                 // wave-uniform; h +- 2^23 cannot wrap
-    const bool up = below(h) <= kt;                            // the key is >= h
-    const unsigned T2 = up ? h + 0x00800000u : h - 0x00800000u;
-    const bool c2 = below(T2) <= kt;                           // the key is >= T2
-    bracket = up ? !c2 : c2;
-    if (bracket) lo = up ? h : T2;                             // the key lies in [lo, lo + 2^23)
-  }
-  if (bracket) {
-#pragma unroll
-    for (int b = 22; b >= 20; --b) {
-      const unsigned T = lo + (1u << b);
-      if (below(T) <= kt) lo = T;
+    const int c1 = below(h);                                   // <= kt: the key is >= h
+    const unsigned T2 = c1 <= kt ? h + 0x00800000u : h - 0x00800000u;
+    const int c2 = below(T2);                                  // <= kt: the key is >= T2
+    if ((c1 <= kt) != (c2 <= kt)) {                            // the key lies between h and T2: in [lo, lo + 2^23)
+      lo = c1 <= kt ? h : T2;
+      full = false;
     }
-  } else {
+  }
+  if (full) {                                                // no guess, or not near it: bits 31 .. 23 from the full range
 #pragma unroll
-    for (int b = 31; b >= 20; --b) {
+    for (int b = 31; b >= 23; --b) {
       const unsigned T = lo | (1u << b);
       if (below(T) <= kt) lo = T;
     }
   }
-  for (int bit = 19; bit >= 0; bit -= 4) {                   // the key lies in [lo, lo + 2^(bit+1)); lo need not be aligned
+#pragma unroll
+  for (int b = 22; b >= 20; --b) {                           // the key lies in [lo, lo + 2^(b+1)); lo need not be aligned
+    const unsigned T = lo + (1u << b);
+    if (below(T) <= kt) lo = T;
+  }
+  for (int bit = 19; bit >= 0; bit -= 4) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const unsigned T = lo + (1u << (bit - j));
@@ -921,10 +922,8 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
         const int d = r >> 5, sh = r & 31;
         const unsigned long long two = ((unsigned long long)s_m32[d + 1] << 32) | s_m32[d];
         const unsigned inv = ~(unsigned)(two >> sh);      // bit 0 (the rise itself) is clear
-        int f = -1;
-        if (inv) {
-          f = r + __builtin_ctz(inv);
-        } else {
+        int f = inv ? r + __builtin_ctz(inv) : -1;
+        if (inv == 0u) {                                    // rare: the pulse is longer than those 32 - sh samples
           int wd = d + 1;
           unsigned cur = ~s_m32[wd] & (~0u << sh);
           while (cur == 0u && ++wd < kMaskDwords) cur = ~s_m32[wd];

@@ -254,11 +254,12 @@ struct adsb_ctx {
   bool own_stream = false;
   int n_cu = 256;
   int bpc[ADSB_FMT_COUNT] = {4, 4, 4, 4, 4};  // resident k_detect workgroups per CU (occupancy query), per input format
-  // Unused dynamic LDS per k_detect workgroup = how many workgroups share a CU.  complex64 (VGPR-limited) runs five per
-  // CU; the narrower formats would fit six, but measured FOUR per CU fastest (int16: 1043 vs 919 Gsamples/s with six,
-  // 930 with three; MI355X, tools/r3_variants.sh): 6 KB of padding lifts a workgroup over the 32 KB that five per CU allow
-  // and still leaves room for the tail kernels of the previous pass beside it.
-  unsigned det_dyn_lds[ADSB_FMT_COUNT] = {0, 6144, 6144, 6144, 6144};
+  // Unused dynamic LDS per k_detect workgroup = how many workgroups share a CU (28.3 KB static: five fit).  Measured per
+  // format on MI355X (tools/r3_variants.sh, 2^30 samples): five per CU for complex64, int16 (+1.4 % over four) and the
+  // 8-bit formats (int8 +8.3 %, uint8 +8.7 % over four; three: -24 %); FOUR for float |IQ|^2 (five: -2.5 %) -- 6 KB of
+  // padding lifts a workgroup over the 32 KB that five per CU allow.  (Earlier in round 3, with more vector
+  // instructions per sample, four was fastest for every narrow format: the choice follows the instruction mix.)
+  unsigned det_dyn_lds[ADSB_FMT_COUNT] = {0, 6144, 0, 0, 0};
   unsigned lds_beside[ADSB_FMT_COUNT] = {0, 0, 0, 0, 0};    // LDS a CU has left beside its resident k_detect workgroups
   // integer IQ component -> float32 multiplier per format (adsb_set_format_scale); unused for the float formats
   float scale[ADSB_FMT_COUNT] = {1.0f, 1.0f, 1.0f / 32768.0f, 1.0f / 128.0f, 1.0f / 255.0f};

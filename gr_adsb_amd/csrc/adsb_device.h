@@ -1225,18 +1225,20 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total) {
 // k_detect of the next pass by 0.03 ms; the same kernel with coalesced accesses costs it nothing.)  2 KB of LDS and
 // few registers on purpose: this workgroup is meant to fit on a CU BESIDE five resident k_detect workgroups (which
 // leave 3.8 KB of LDS -- in whole 1280-byte allocation granules -- and 112 VGPRs per SIMD free).
-#ifndef ADSB_SCAN_ROUND
-#define ADSB_SCAN_ROUND 512
-#endif
-constexpr int kScanRound = ADSB_SCAN_ROUND;
-constexpr int kScanPer = kScanRound / kThreads;      // consecutive lists per thread and round
+// A bulk pass with thousands of lists (k_detect runs several resident rounds of short chunks, adsb_hip.hip: enqueue)
+// stages kScanRoundBig lists per round in the 8 KB of dynamic LDS the launch carries anyway (its padding, see
+// enqueue_tail): a round costs about a microsecond of load latency and barriers whatever its size.
+constexpr int kScanRound = 512;
+constexpr int kScanRoundBig = 2048;
+template <int ROUND>
 __device__ __forceinline__ void scan_body(const int* blk_count, const long long* blk_lastp,
                                           const unsigned* blk_flags, int nblk, int rec_cap,
                                           const int* long_count, const unsigned long long* long_lastp,
-                                          int* blk_off, Summary* sum) {
+                                          int* blk_off, Summary* sum, int* s_cnt) {
+  constexpr int kScanRound = ROUND;
+  constexpr int kScanPer = ROUND / kThreads;         // consecutive lists per thread and round
   __shared__ long long s_lp[kWaves];
   __shared__ unsigned s_fl[kWaves];
-  __shared__ int s_cnt[kScanRound];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   long long lp = kNoIndex; unsigned fl = 0;
   int carry = 0;                                               // lists before this round hold `carry` centres
@@ -1288,8 +1290,13 @@ __device__ __forceinline__ void scan_body(const int* blk_count, const long long*
 __global__ void __launch_bounds__(kThreads) k_scan(const int* blk_count, const long long* blk_lastp,
                                                    const unsigned* blk_flags, int nblk, int rec_cap,
                                                    const int* long_count, const unsigned long long* long_lastp,
-                                                   int* blk_off, Summary* sum) {
-  scan_body(blk_count, blk_lastp, blk_flags, nblk, rec_cap, long_count, long_lastp, blk_off, sum);
+                                                   int* blk_off, Summary* sum, int dyn_ints) {
+  ADSB_DYN_LDS_INT(s_scan_dyn);                                 // the launch's dynamic LDS (0 or 8 KB)
+  __shared__ int s_scan_cnt[kScanRound];
+  if (dyn_ints >= kScanRoundBig)                                // wave-uniform
+    scan_body<kScanRoundBig>(blk_count, blk_lastp, blk_flags, nblk, rec_cap, long_count, long_lastp, blk_off, sum, s_scan_dyn);
+  else
+    scan_body<kScanRound>(blk_count, blk_lastp, blk_flags, nblk, rec_cap, long_count, long_lastp, blk_off, sum, s_scan_cnt);
 }
 
 // ---- k_gather: per-unit lists of centre words -> one list in stream order; the burst records stay where k_detect wrote
@@ -1300,12 +1307,15 @@ __global__ void __launch_bounds__(kThreads) k_scan(const int* blk_count, const l
 __device__ __forceinline__ void gather_body(int bid, int nb, const unsigned long long* cands, const int* blk_count,
                                             const int* blk_off, int nblk, int rec_cap, unsigned long long* sorted,
                                             unsigned* sorted_src) {
-  for (int b = bid; b < nblk; b += nb) {
+  // one WAVEFRONT per list: a bulk pass has tens of thousands of short lists (a dozen centres each), and a list costs
+  // its two dependent reads whatever its length
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = bid * kWaves + wave; b < nblk; b += nb * kWaves) {
     int c = blk_count[b];
     if (c > rec_cap) c = rec_cap;
     const int off = blk_off[b];
     const long long src = (long long)b * rec_cap;
-    for (int j = threadIdx.x; j < c; j += kThreads) {
+    for (int j = lane; j < c; j += 64) {
       sorted[off + j] = cands[src + j];
       sorted_src[off + j] = (unsigned)(src + j);           // where its 32-byte record lies: it is read once, by k_compact
     }
@@ -1472,7 +1482,8 @@ template <int MODE>
 __global__ void __launch_bounds__(kThreads) k_tail_small(DetectArgs a, TailArgs t) {
   longrun_body<MODE>(0, 1, a);                                // pulses longer than k_detect's LDS window (usually none)
   __syncthreads();
-  scan_body(t.blk_count, t.blk_lastp, t.blk_flags, t.nblk, t.rec_cap, t.long_count, t.long_lastp, t.blk_off, t.sum);
+  __shared__ int s_scan_cnt[kScanRound];
+  scan_body<kScanRound>(t.blk_count, t.blk_lastp, t.blk_flags, t.nblk, t.rec_cap, t.long_count, t.long_lastp, t.blk_off, t.sum, s_scan_cnt);
   __syncthreads();
   gather_body(0, 1, t.cands, t.blk_count, t.blk_off, t.nblk, t.rec_cap, t.sorted, t.sorted_src);
   __syncthreads();
@@ -1501,7 +1512,8 @@ __global__ void __launch_bounds__(kThreads) k_pass_small(DetectArgs a, TailArgs 
   __syncthreads();
   longrun_body<1>(0, 1, a);
   __syncthreads();
-  scan_body(t.blk_count, t.blk_lastp, t.blk_flags, t.nblk, t.rec_cap, t.long_count, t.long_lastp, t.blk_off, t.sum);
+  __shared__ int s_scan_cnt[kScanRound];
+  scan_body<kScanRound>(t.blk_count, t.blk_lastp, t.blk_flags, t.nblk, t.rec_cap, t.long_count, t.long_lastp, t.blk_off, t.sum, s_scan_cnt);
   __syncthreads();
   gather_body(0, 1, t.cands, t.blk_count, t.blk_off, t.nblk, t.rec_cap, t.sorted, t.sorted_src);
   __syncthreads();

@@ -195,6 +195,7 @@ inline void adsb_wave_sync() {
 
 inline int adsb_uniform(int v) { return v; }
 inline int adsb_opaque(int v) { return v; }
+#define ADSB_DYN_LDS_INT(name) static int name[2048]
 inline unsigned adsb_after(unsigned v, float) { return v; }
 #define ADSB_LDS
 template <class Q> inline Q adsb_ld_stream(const char* p) { Q q; memcpy(&q, p, sizeof(Q)); return q; }

@@ -127,7 +127,8 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     SIM_BY_MODE(mode, k_longrun, 3, kThreads, a);
     hipsim::launch(k_scan, 1, kThreads, (const int*)blk_count.data(), (const long long*)blk_lastp.data(),
                    (const unsigned*)blk_flags.data(), nlists, rec_cap, (const int*)&long_count,
-                   (const unsigned long long*)&long_lastp, blk_off.data(), &sum);
+                   (const unsigned long long*)&long_lastp, blk_off.data(), &sum,
+                   (nlists % 3) ? 2048 : 0);                  // both staging sizes get exercised (same result either way)
     hipsim::launch(k_gather, nlists < 8 ? nlists : 8, kThreads, (const unsigned long long*)cands.data(),
                    (const int*)blk_count.data(), (const int*)blk_off.data(), nlists, rec_cap, sorted.data(), sorted_src.data());
     unsigned fmask = 0u, fwant = 0u;

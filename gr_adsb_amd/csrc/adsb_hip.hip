@@ -465,11 +465,12 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   if (ntiles < 1) ntiles = 1;
   const int bpc = c->bpc[pl.mode];
   // Chunks: one resident round of wavefronts is the floor; a bulk pass is cut into up to kRounds rounds of shorter chunks
-  // (not shorter than kMinChunkTiles tiles): the wavefronts of ONE round each with 1/5120 of the stream finish up to 10 %
-  // apart (their burst counts differ), and the kernel ends with its slowest wavefront -- with eight rounds the
-  // dispatcher evens that out (measured, 2^30 complex64 samples: 0.78 -> 0.82 of the HBM peak; 16 rounds: 0.80 and a
-  // longer tail chain; int8: best at 4-8).  A PARTIAL second round is the worst case (+20 %), hence whole multiples.
-  constexpr int kRounds = 8, kMinChunkTiles = 8;
+  // (not shorter than kMinChunkTiles tiles).  The wavefronts of ONE round, each with 1/5120 of the stream, finish up to
+  // 10 % apart (their burst counts differ) and the kernel ends with its slowest wavefront; with several rounds the
+  // dispatcher evens that out.  Measured on MI355X (tools/r3_variants.sh): 2^30 complex64 samples 0.74 -> 0.79-0.81 of
+  // the HBM peak with 8 rounds (16: the same for complex64, -6 % for int8 / int16; 4: -3 %), 2^28 samples 0.72 -> 0.79
+  // with chunks down to 4 tiles (8: 0.77), 2^26 samples +1 %.
+  constexpr int kRounds = 8, kMinChunkTiles = 4;
   const long long resident = (long long)c->n_cu * bpc * upb;
   long long rounds = ntiles / (resident * kMinChunkTiles);
   if (rounds < 1) rounds = 1;

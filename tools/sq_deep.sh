@@ -5,6 +5,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/$1; shift
 cd /tmp
+mkdir -p $(dirname $OUT)
 CFGS=("--log2n 30 --format sc8" "--log2n 30")
 if [ $# -gt 0 ]; then CFGS=("$@"); fi
 PASSES=("SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS"

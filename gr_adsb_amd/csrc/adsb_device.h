@@ -1243,17 +1243,24 @@ __device__ __forceinline__ void scan_body(const int* blk_count, const long long*
   long long lp = kNoIndex; unsigned fl = 0;
   int carry = 0;                                               // lists before this round hold `carry` centres
   for (int base = 0; base < nblk; base += kScanRound) {
-    for (int k = tid; k < kScanRound; k += kThreads) {         // coalesced: counts to LDS, max / OR reduced on the fly
-      const int b = base + k;
-      int c = 0;
-      if (b < nblk) {
-        c = blk_count[b];
-        if (c > rec_cap) { fl |= 0x80000000u; c = rec_cap; }  // bit 31: some unit overflowed its list
-        const long long l = blk_lastp[b];
-        if (l > lp) lp = l;
-        fl |= blk_flags[b];
-      }
-      s_cnt[k] = c;
+    // coalesced: counts to LDS, max / OR reduced on the fly.  All loads of the round are issued before any is used
+    // (clamped index, result masked): one memory latency per round, not one per 256 lists
+    int cc[kScanPer];
+    long long ll[kScanPer];
+    unsigned ff[kScanPer];
+#pragma unroll
+    for (int q = 0; q < kScanPer; ++q) {
+      const int b = base + q * kThreads + tid, bc = b < nblk ? b : nblk - 1;
+      cc[q] = blk_count[bc]; ll[q] = blk_lastp[bc]; ff[q] = blk_flags[bc];
+    }
+#pragma unroll
+    for (int q = 0; q < kScanPer; ++q) {
+      const bool in = base + q * kThreads + tid < nblk;
+      int c = in ? cc[q] : 0;
+      if (c > rec_cap) { fl |= 0x80000000u; c = rec_cap; }    // bit 31: some unit overflowed its list
+      if (in && ll[q] > lp) lp = ll[q];
+      if (in) fl |= ff[q];
+      s_cnt[q * kThreads + tid] = c;
     }
     __syncthreads();
     int acc = 0;

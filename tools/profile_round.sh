@@ -68,7 +68,7 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace
 python $ROOT/tools/pmc_summary.py $(find $W/sq1 -name '*counter_collection.csv' | head -1) \
                                   $(find $W/sq2 -name '*counter_collection.csv' | head -1) > $OUT/${R}_pmc_sq_counters.txt 2>&1
 # 4b. where k_detect's cycles go (per-class active cycles, LDS conflicts): int8 and complex64 at 2^30
-bash $ROOT/tools/sq_deep.sh gpurun_out/prof/${R}_sq_deep.txt > /dev/null 2>&1
+(cd $ROOT && bash tools/sq_deep.sh gpurun_out/prof/${R}_sq_deep.txt > /dev/null 2>&1)
 # 5. the full default bench line (CPU baselines, bit-match, host-fed per format, extra_configs), unprofiled
 cd $ROOT
 $S $W/full.clk -- python bench.py > $OUT/${R}_bench_unprofiled.json 2>> $W/bench.err

@@ -904,12 +904,24 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
   ntile = adsb_uniform(ntile); it_re = adsb_uniform(it_re); it_i0 = adsb_uniform(it_i0); it_i1 = adsb_uniform(it_i1);
   it_rag = adsb_uniform(it_rag); it_e0 = adsb_uniform(it_e0); it_e1 = adsb_uniform(it_e1);
 
-  if (ntile > 0) {
-    // head of the window and back halo of the first tile (later tiles inherit both): once per unit and launch
-    for (int i = lane; i < kBack + kFwd; i += 64) s_x[i - kBack] = xg<MODE>(a.data, a.n, c0 - kBack + i, a.scale);
+  // Head of the window and back halo of the first tile (later tiles inherit both): once per chunk -- and a bulk pass has
+  // tens of thousands of chunks: all six loads of a lane are in flight together (clamped index, value selected afterwards),
+  // and the streaming loop issues the first body's loads BEFORE it fills the head: one memory latency at the start of a
+  // chunk instead of seven in a row.
+  auto head_fill = [&](const int lane) {
+    constexpr int NQ = (kBack + kFwd) / 64;
+    if (a.n > 0) {                                             // wave-uniform
+      float hv[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) hv[q] = xg_nb<MODE>(a.data, a.n, c0 - kBack + lane + 64 * q, a.scale);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) s_x[lane + 64 * q - kBack] = hv[q];
+    } else {
+      for (int i = lane; i < kBack + kFwd; i += 64) s_x[i - kBack] = 0.0f;
+    }
     adsb_wave_sync();
     s_m16[lane & (kHeadUnits - 1)] = (unsigned short)unit_mask(s_x + kUnit * (lane & (kHeadUnits - 1)), thr);
-  }
+  };
   bool prev_active = true;                                   // the head units were computed exactly
 
   // -- B.2 one lane per rise: fall, centre, 16-chip test (framer.py:113,137-147); hits are compacted in order over the
@@ -1091,7 +1103,10 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
     const char* const clamp = reinterpret_cast<const char*>(a.data) + (((a.n - kWTile) * (long long)BPS) & ~15ll);
     const char* nb = reinterpret_cast<const char*>(a.data) + (c0 + kFwd) * (long long)BPS;      // this tile's body
     Body<MODE> body;
-    if (ntile > 0) body_issue(body, it_rag > 0 ? nb : clamp, lane);
+    if (ntile > 0) {
+      body_issue(body, it_rag > 0 ? nb : clamp, lane);
+      head_fill(lane);
+    }
     for (int it = 0; it < ntile; ++it) {
       // The lane number through an opaque copy, renewed every tile: otherwise lane-derived addresses are hoisted out of
       // this loop as loop-invariant registers, which the register budget of five wavefronts per SIMD cannot hold.
@@ -1108,6 +1123,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
     }
   } else {
     // -- inputs shorter than one tile (a GNU Radio work() call of a few hundred samples): scalar reads only
+    if (ntile > 0) head_fill(lane_outer);
     for (int it = 0; it < ntile; ++it) {
       const int lane = adsb_opaque(lane_outer);
       const long long t0 = c0 + (long long)it * kWTile;

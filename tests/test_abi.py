@@ -177,8 +177,8 @@ def test_head_sync_predicts_fixup_and_fixup_is_exact(native):
 
 
 def test_kernel_resources_keep_the_tail_co_resident():
-    """The pipelined pass rate depends on a resource fact, not only on code: k_detect launches exactly one resident round
-    of workgroups (5 per CU), and the sparse tail kernels of the PREVIOUS pass run beside it.  If they do not fit in
+    """The pipelined pass rate depends on a resource fact, not only on code: k_detect keeps five workgroups resident per CU
+    (in one to eight rounds), and the sparse tail kernels of the PREVIOUS pass run beside them.  If they do not fit in
     what five k_detect workgroups leave free on a CU, they run when k_detect drains and the next k_detect starts with
     some of its workgroups in a second round (measured: 1.89 instead of 1.51 ms per pass when k_detect took 96 VGPRs).
     The compiler's own report (written by gr_adsb_amd.build) is checked against those limits here."""

@@ -42,7 +42,7 @@ EXPORTS = [
     "adsb_set_iq16_scale", "adsb_process_iq16", "adsb_process_iq16_device",
     "adsb_set_format_scale", "adsb_process_format", "adsb_process_format_device", "adsb_submit_format_device",
     "adsb_submit_format_host", "adsb_last_confidence",
-    "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_shard_host", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_mode_s_syndrome", "adsb_get_stats",
+    "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_shard_host", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_mode_s_syndrome", "adsb_plan_chunks", "adsb_get_stats",
     "adsb_reset_stats", "adsb_last_error", "adsb_host_alloc", "adsb_host_free", "adsb_host_register", "adsb_host_unregister",
 ]
 
@@ -121,6 +121,8 @@ def load():
     lib.adsb_snr_db.restype = f32
     lib.adsb_mode_s_syndrome.argtypes = [vp, c.POINTER(i32), c.POINTER(i32)]
     lib.adsb_mode_s_syndrome.restype = c.c_uint32
+    lib.adsb_plan_chunks.argtypes = [i64, i64, c.POINTER(i64), c.POINTER(i64)]
+    lib.adsb_plan_chunks.restype = c.c_int32
     lib.adsb_get_stats.argtypes = [vp, c.POINTER(Stats)]
     lib.adsb_reset_stats.argtypes = [vp]
     lib.adsb_host_alloc.argtypes = [c.POINTER(vp), c.c_size_t]
@@ -520,6 +522,15 @@ def burst_df(recs):
 def parity_ok(recs):
     """True where the decoder's check_parity() will pass without an aircraft table (DF 11/17/18/19, syndrome 0)."""
     return (recs["flags"] & BURST_PARITY_OK) != 0
+
+
+def plan_chunks(n_samples, resident_wavefronts):
+    """(units, samples_per_chunk) of one call over n_samples (adsb_plan_chunks: pure host arithmetic)."""
+    u, t = ctypes.c_int64(), ctypes.c_int64()
+    rc = load().adsb_plan_chunks(int(n_samples), int(resident_wavefronts), ctypes.byref(u), ctypes.byref(t))
+    if rc != 0:
+        raise AdsbError(rc, "adsb_plan_chunks")
+    return u.value, t.value
 
 
 def mode_s_syndrome(bits14):

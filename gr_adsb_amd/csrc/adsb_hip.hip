@@ -464,21 +464,9 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   long long ntiles = (s.span + tile - 1) / tile;
   if (ntiles < 1) ntiles = 1;
   const int bpc = c->bpc[pl.mode];
-  // Chunks: one resident round of wavefronts is the floor; a bulk pass is cut into up to kRounds rounds of shorter chunks
-  // (not shorter than kMinChunkTiles tiles).  The wavefronts of ONE round, each with 1/5120 of the stream, finish up to
-  // 10 % apart (their burst counts differ) and the kernel ends with its slowest wavefront; with several rounds the
-  // dispatcher evens that out.  Measured on MI355X (tools/r3_variants.sh): 2^30 complex64 samples 0.74 -> 0.79-0.81 of
-  // the HBM peak with 8 rounds (16: the same for complex64, -6 % for int8 / int16; 4: -3 %), 2^28 samples 0.72 -> 0.79
-  // with chunks down to 4 tiles (8: 0.77), 2^26 samples +1 %.
-  constexpr int kRounds = 8, kMinChunkTiles = 4;
-  const long long resident = (long long)c->n_cu * bpc * upb;
-  long long rounds = ntiles / (resident * kMinChunkTiles);
-  if (rounds < 1) rounds = 1;
-  if (rounds > kRounds) rounds = kRounds;
-  const long long umax = resident * rounds;
-  long long units = ntiles < umax ? ntiles : umax;
-  const long long tiles_per = (ntiles + units - 1) / units;
-  units = (ntiles + tiles_per - 1) / tiles_per;
+  // chunks: one resident round of wavefronts is the floor, a bulk pass runs up to eight rounds of shorter ones (adsb_plan.h)
+  long long units = 0, tiles_per = 0;
+  plan_chunks(ntiles, (long long)c->n_cu * bpc * upb, &units, &tiles_per);
   const long long chunk = tiles_per * tile;
   // k_detect keeps pulse centres relative to the start of a unit's chunk in 32 bits
   if (chunk >= (1ll << 30)) return fail(c, -EINVAL, "input too long for one call on this device (chunk per wavefront >= 2^30 samples)");
@@ -733,6 +721,14 @@ int upload(adsb_ctx* c, const void* host, size_t bytes, void** d_out) {
 extern "C" {
 
 int adsb_abi_version(void) { return ADSB_ABI_VERSION; }
+
+int32_t adsb_plan_chunks(int64_t n_samples, int64_t resident_wavefronts, int64_t* units, int64_t* samples_per_chunk) {
+  if (n_samples < 0 || resident_wavefronts < 1 || !units || !samples_per_chunk) return -EINVAL;
+  long long u = 0, t = 0;
+  plan_chunks((n_samples + kWTile - 1) / kWTile, resident_wavefronts, &u, &t);
+  *units = u; *samples_per_chunk = t * kWTile;
+  return 0;
+}
 
 uint32_t adsb_mode_s_syndrome(const uint8_t bits[14], int32_t* df_out, int32_t* nbits_out) {
   // decoder.py:551 (DF), :565,604,636,669 (format sets), :693-714 (compute_crc); same table as the device

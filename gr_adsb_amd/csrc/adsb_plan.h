@@ -25,6 +25,30 @@ struct Plan {
   bool long_aware = false;  // opt-in length-aware gate (never in GNU Radio emulation): set by the caller from the context
 };
 
+// How a pass over `ntiles` tiles (1024 samples each) is cut into chunks, one per wavefront, for a device that keeps
+// `resident` wavefronts of k_detect resident at a time.  One resident round is the floor (units == ntiles while there
+// are fewer tiles than resident wavefronts); a bulk pass is cut into up to kChunkRounds rounds of shorter chunks, none
+// shorter than kMinChunkTiles tiles: the wavefronts of ONE round, each with 1/resident of the stream, finish up to 10 %
+// apart (their burst counts differ) and the kernel ends with its slowest wavefront; with several rounds the dispatcher
+// evens that out.  Measured on MI355X (tools/r3_variants.sh): 2^30 complex64 samples 0.74 -> 0.79-0.82 of the HBM peak
+// with 8 rounds (16: the same for complex64, -6 % for int8 / int16; 4: -3 %), 2^28 samples 0.72 -> 0.79 with chunks
+// down to 4 tiles (8: 0.77), 2^26 samples +1 %.
+// Out: *units wavefronts with work, each *tiles_per tiles long (the last may be shorter): units * tiles_per >= ntiles.
+constexpr int kChunkRounds = 8, kMinChunkTiles = 4;
+inline void plan_chunks(long long ntiles, long long resident, long long* units_out, long long* tiles_per_out) {
+  if (ntiles < 1) ntiles = 1;
+  if (resident < 1) resident = 1;
+  long long rounds = ntiles / (resident * kMinChunkTiles);
+  if (rounds < 1) rounds = 1;
+  if (rounds > kChunkRounds) rounds = kChunkRounds;
+  const long long umax = resident * rounds;
+  long long units = ntiles < umax ? ntiles : umax;
+  const long long tiles_per = (ntiles + units - 1) / units;
+  units = (ntiles + tiles_per - 1) / tiles_per;
+  *units_out = units;
+  *tiles_per_out = tiles_per;
+}
+
 struct FramerState {
   float prev_in0 = 0.0f;    // framer.py:54
   long long prev_eob = -1;  // framer.py:57 (index into the NEXT call's in0)

@@ -279,6 +279,14 @@ float adsb_snr_db(float peak, float median);
  * Pure host arithmetic on one 14-byte payload; out pointers may be NULL. */
 uint32_t adsb_mode_s_syndrome(const uint8_t bits[14], int32_t* df, int32_t* nbits);
 
+/* How one call over n_samples is cut on a device that keeps `resident_wavefronts` wavefronts of the streaming kernel
+ * resident (adsb_stats.detect_grid / blocks_per_cu tell what a context uses: CUs x blocks_per_cu x 4): *units chunks of
+ * *samples_per_chunk samples each (the last may be shorter), one wavefront and one output list per chunk.  One resident
+ * round is the floor; a bulk call runs up to eight rounds of shorter chunks (never shorter than 4096 samples) so that the
+ * dispatcher evens out wavefronts that finish apart.  Pure host arithmetic (no device needed), the reference has no
+ * counterpart: framer.py:83-174 walks the whole in0 in one Python loop.  Returns 0 or -EINVAL. */
+int32_t adsb_plan_chunks(int64_t n_samples, int64_t resident_wavefronts, int64_t* units, int64_t* samples_per_chunk);
+
 int adsb_get_stats(adsb_ctx* ctx, adsb_stats* out);
 int adsb_reset_stats(adsb_ctx* ctx);
 /* Text of the last error on this context ("" if none). */

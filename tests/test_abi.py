@@ -203,3 +203,36 @@ def test_kernel_resources_keep_the_tail_co_resident():
             assert alloc(t["vgprs"]) <= free_vgpr, "%s (%d VGPRs) does not fit beside %s (%d)" % (tname, t["vgprs"], name, d["vgprs"])
             assert gran(t["lds_bytes_per_block"]) <= free_lds, "%s (%d B LDS) does not fit beside %s" % (tname, t["lds_bytes_per_block"], name)
             assert t["scratch_bytes_per_lane"] == 0, tname
+
+
+def test_chunk_plan_covers_the_call_and_keeps_its_limits(native):
+    """adsb_plan_chunks (pure host arithmetic, the function enqueue() cuts every call with): the chunks cover the call,
+    one resident round is the floor, a bulk call gets at most eight rounds of chunks no shorter than four tiles, and more
+    samples never mean fewer than half the chunks."""
+    T = 1024
+    for resident in (4, 1024, 4096, 5120):
+        prev_units = 0
+        for n in [1, 100, T, T + 1, 37 * T, resident * T - 1, resident * T, resident * T + 1, 3 * resident * T + 5,
+                  4 * resident * T, 4 * resident * T + 1, 9 * resident * T, 31 * resident * T + 7, 32 * resident * T,
+                  33 * resident * T, 200 * resident * T + 123, 1 << 30, (1 << 31) + (1 << 20) + 37]:
+            units, per = native.plan_chunks(n, resident)
+            ntiles = -(-n // T)
+            assert per % T == 0 and per >= T
+            assert units * per >= n and (units - 1) * per < ntiles * T          # covers, and no empty trailing chunk
+            assert units <= max(ntiles, 1) and units <= 8 * resident
+            if ntiles <= resident:
+                assert units == ntiles and per == T                             # one tile per wavefront
+            if units > resident:
+                assert per >= 4 * T                                             # several rounds: chunks of >= 4 tiles
+            if ntiles >= 32 * resident:
+                assert units > 6 * resident                                     # a bulk call uses (about) eight rounds
+            if n >= resident * T:                                               # (chunks are whole tiles of one length: just over a
+                assert 2 * units >= prev_units                                  #  round, two tiles each need half the wavefronts)
+            prev_units = units
+    # the bench sizes on an MI355X context (256 CUs x 5 workgroups x 4 wavefronts)
+    assert native.plan_chunks(1 << 30, 5120) == (40330, 26 * T)
+    assert native.plan_chunks(1 << 26, 5120)[1] == 5 * T
+    with pytest.raises(native.AdsbError):
+        native.plan_chunks(-1, 5120)
+    with pytest.raises(native.AdsbError):
+        native.plan_chunks(1 << 20, 0)

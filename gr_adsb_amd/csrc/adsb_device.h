@@ -349,13 +349,9 @@ __device__ __forceinline__ BurstFetch<MODE> burst_issue(const DetectArgs& a, uns
   return f;
 }
 
-// The part of a burst record every path shares, once the wavefront holds the burst's samples: lane l has window
-// samples l and l+64 (v0, v1; valid iff val0, val1; nwin = window length, framer.py:156), bit-pair l (x1, x0) and,
-// for l < 48, bit-pair 64+l (y1, y0) (demod.py:87-92); peak = in0[pulse_idx].  `dem` = the burst ends inside the demod
-// input (demod.py:82).  xflags: record flags already known (kRecLongHint; the tail adds kKept / kHead).  Lane 0
-// stores the 32-byte record.
 // np.median of the noise window held by a wavefront (framer.py:156-159): lane l has window samples l and l + 64 (v0, v1;
-// valid iff val0, val1; nwin = window length).  Wave-uniform result.
+// valid iff val0, val1; nwin = window length).  Wave-uniform result.  `hint` (wave-uniform, in and out): the key this
+// function found for the wavefront's previous burst, 0 = none -- a first guess that is proved before it is used.
 __device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, float v0, float v1, unsigned& hint) {
   const unsigned long long nanm = __ballot((val0 && v0 != v0) || (val1 && v1 != v1));
   const unsigned k0 = val0 ? f32_key(v0) : 0xFFFFFFFFu;      // lanes outside the window sort last
@@ -366,7 +362,8 @@ __device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, fl
   const int kt = adsb_uniform((nwin - 1) >> 1);
   unsigned lo = 0u, span = 0u;
   bool single = false;
-  // Eight rounds of four steps.  After 16, 20 and 24 decided bits: what does the interval [lo, lo + 2^bit) hold?  Exactly
+  // Steps of one bit (from the full range: 32; from a proved guess: 23).  After 16, 20 and 24 decided bits: what does the
+  // interval [lo, lo + 2^bit) hold?  Exactly
   // one key: that key IS the answer -- the usual case for float noise after 16 bits (half the steps).  Four or more keys
   // that are all EQUAL (minimum == maximum of the keys inside): that value is the answer -- the usual case for streams
   // quantised to a few levels (8-bit IQ), whose median sits in a crowd of duplicates.  Otherwise on with the search.
@@ -466,6 +463,10 @@ __device__ __forceinline__ void rec_store_bits(Rec* out, unsigned long long ma, 
   }
 }
 
+// The record of a burst whose samples a wavefront holds in registers (k_longrun): lane l has window samples l and l+64
+// (v0, v1; valid iff val0, val1; nwin = window length, framer.py:156), bit-pair l (x1, x0) and, for l < 48, bit-pair 64+l
+// (y1, y0) (demod.py:87-92); peak = in0[pulse_idx].  `dem` = the burst ends inside the demod input (demod.py:82).
+// xflags: record flags already known (kRecLongHint; the tail adds kKept / kHead).  Lane 0 stores the 32-byte record.
 __device__ __forceinline__ void burst_reduce(long long offset, int nwin, bool val0, bool val1, float peak, float v0,
                                              float v1, bool dem, float x1, float x0, float y1, float y0, unsigned xflags,
                                              Rec* out, int lane) {

@@ -44,10 +44,8 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   const int tile = kWTile;
   long long ntiles = (span + tile - 1) / tile;
   if (ntiles < 1) ntiles = 1;
-  const long long umax = (long long)grid_max * upb;
-  long long units = ntiles < umax ? ntiles : umax;
-  const long long tiles_per = (ntiles + units - 1) / units;
-  units = (ntiles + tiles_per - 1) / tiles_per;
+  long long units = 0, tiles_per = 0;
+  plan_chunks(ntiles, (long long)grid_max * upb, &units, &tiles_per);     // adsb_plan.h: the library's own chunk / round policy
   const long long chunk = tiles_per * tile;
   const int grid = (int)((units + upb - 1) / upb);
   const int nlists = grid * upb;

@@ -281,6 +281,43 @@ def test_many_units():
     assert len(recs) > 200
 
 
+@pytest.mark.parametrize("fs,bps,mode,grid_max", [(2e6, 4000, 0, 1), (8e6, 6000, 1, 2), (20e6, 9000, 3, 1), (2e6, 3000, 4, 2)])
+def test_bulk_pass_in_several_rounds_of_short_chunks(fs, bps, mode, grid_max):
+    """A call with many more tiles than resident wavefronts is cut into up to eight rounds of chunks of four tiles or more
+    (adsb_plan.h: plan_chunks, the function the library's enqueue() uses): every chunk fills its own window head (six loads
+    per lane in flight together, samples in front of the buffer and past its end are zeros), the usual-tile instance and the
+    general one alternate at the ends of the call, and the tail orders far more lists than one round has."""
+    n = 200_000
+    T, F, B = simlib.kernel_geometry()
+    ntiles = -(-n // T)
+    units, per = _native_plan(ntiles * T, grid_max * 4)
+    assert units > 4 * grid_max * 4 and per >= 4 * T          # several rounds, short chunks
+    iq = M.synth_iq(n, fs, bps, seed=int(fs // 1e6) + mode)
+    sps = int(fs // 1e6)
+    if mode == 0:
+        data, want = iq, C.canonical(O.mag2(iq), sps, np.float32(0.01))
+        kw = {}
+    elif mode == 1:
+        data = O.mag2(iq)
+        want = C.canonical(data, sps, np.float32(0.01))
+        kw = {}
+    else:
+        q = M.quantize_iq8(iq, full_scale=4.0, offset_binary=(mode == 4))
+        scale = float(np.float32(4.0 / (255.0 if mode == 4 else 127.0)))
+        data, want = q, C.canonical(O.mag2_iq8(q, scale, mode == 4), sps, np.float32(0.01))
+        kw = {"scale": scale}
+    got, so = simlib.sim_canonical(mode, data, fs, 0.01, grid_max=grid_max, **kw)
+    assert so.overflow == 0 and len(want) > 25
+    assert_recs_equal(got, want, "rounds, mode %d" % mode)
+
+
+def _native_plan(n_samples, resident):
+    from gr_adsb_amd import build as b
+    b.build()
+    from gr_adsb_amd import _native
+    return _native.plan_chunks(n_samples, resident)
+
+
 @pytest.mark.parametrize("fs,bps,mode", [(2e6, 6000, 0), (4e6, 5000, 1), (8e6, 6000, 0), (20e6, 3000, 1)])
 def test_long_aware_gate_matches_its_oracle(fs, bps, mode):
     """SURVEY.md §8f-4, opt-in (ADSB_FLAG_LONG_AWARE_GATE): the gate holds 119*sps after a burst whose first data bit is

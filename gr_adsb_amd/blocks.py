@@ -6,7 +6,9 @@ Same constructor arguments, block names, port signatures, history, tag (key "bur
 the C ABI (adsb_framer_work / adsb_demod_work).  With GNU Radio installed these subclass the real
 gr.sync_block; without it they subclass grshim.sync_block so tests can drive them call by call.
 """
+import collections
 import datetime
+import threading
 
 import numpy as np
 
@@ -35,6 +37,65 @@ def make_pdu(start_timestamp, fs, offset, snr, bits112):
         "snr": snr,
     })
     return pmt.cons(meta, pmt.to_pmt(np.ascontiguousarray(bits112, dtype=np.uint8)))
+
+
+class _SliceStore:
+    """Bits the framer's device pass has already sliced, handed to the paired demod (demod(fs, framer=...)).
+
+    GNU Radio runs every block's work() on its own thread, so the framer's put() and the demod's take() race by design:
+    both run under one lock and exchange whole per-call ARRAYS in stream order (a deque of (offsets, bits14, flags), one
+    entry per framer call that produced PDUs) -- no per-burst dictionary traffic.  The demod sees tags in stream order, so
+    take() consumes from the front and forgets everything up to the last offset it was asked for.  Should the demod stall
+    (GNU Radio's bounded buffers normally make that impossible) the oldest calls are forgotten beyond `cap` bursts -- never
+    the newest one, however large -- and the demod then slices those bursts on the device itself (demod.work's fall-back)."""
+
+    def __init__(self, cap=1 << 18):
+        self.cap = int(cap)
+        self.evicted = 0
+        self._n = 0
+        self._q = collections.deque()
+        self._lock = threading.Lock()
+
+    def __len__(self):
+        return self._n
+
+    def put(self, offs, bits14, flags):
+        with self._lock:
+            self._q.append((offs, bits14, flags))
+            self._n += len(offs)
+            while self._n > self.cap and len(self._q) > 1:
+                self._n -= len(self._q[0][0])
+                self.evicted += len(self._q[0][0])
+                self._q.popleft()
+
+    def take(self, offs):
+        """offs: int64, increasing.  Returns (found[n] bool, bits14[n, 14], flags[n]); rows of bursts that are not (or no
+        longer) stored are zero.  Everything stored at or in front of offs[-1] is forgotten."""
+        n = len(offs)
+        found = np.zeros(n, dtype=bool)
+        bits = np.zeros((n, 14), dtype=np.uint8)
+        flags = np.zeros(n, dtype=np.uint16)
+        last = int(offs[-1])
+        with self._lock:
+            while self._q:
+                so, sb, sf = self._q[0]
+                i = np.searchsorted(so, offs)
+                hit = i < len(so)
+                hit[hit] = so[i[hit]] == offs[hit]
+                if hit.any():
+                    found |= hit
+                    bits[hit] = sb[i[hit]]
+                    flags[hit] = sf[i[hit]]
+                if int(so[-1]) <= last:                     # consumed to its end
+                    self._n -= len(so)
+                    self._q.popleft()
+                    continue
+                k = int(np.searchsorted(so, last, side="right"))
+                if k:                                       # the demod's chunk ended inside this framer call: keep the rest
+                    self._q[0] = (so[k:], sb[k:], sf[k:])
+                    self._n -= k
+                break
+        return found, bits, flags
 
 
 class framer(gr.sync_block):
@@ -85,8 +146,9 @@ class framer(gr.sync_block):
         self._ctx = _native.Context(fs, threshold, device=device,
                                     flags=(_native.FLAG_LONG_AWARE_GATE if self.long_aware else 0) |
                                           (0 if self.improved else _native.FLAG_FRAMER_SLICES))
-        self._sliced = {}                 # tag offset -> (bits14, flags) of the tags this block emitted with bits
-        self._sliced_cap = 8192
+        self._slices = _SliceStore()      # bits of the bursts this block's pass already sliced, for a paired demod
+        self._paired = False              # set by demod(fs, framer=self): only then are the slices kept
+        self._pmt_key, self._pmt_src = pmt.to_pmt("burst"), pmt.to_pmt("framer")
 
     def set_threshold(self, threshold):
         self.threshold = threshold            # read once per work(), like the reference (framer.py:84)
@@ -140,21 +202,17 @@ class framer(gr.sync_block):
         if self.improved:
             return self._work_improved(in0, out0)
         bursts = self._ctx.framer_work(in0[:N + self.N_hist - 1], N, self.nitems_written(0))
-        snr = _native.snr_db(bursts["peak"], bursts["median"]) if len(bursts) else ()     # (most work() calls carry no burst)
-        if len(bursts):
-            if len(self._sliced) > self._sliced_cap:      # nobody collects them (no paired demod): forget the oldest
-                for k in sorted(self._sliced)[:len(self._sliced) - self._sliced_cap // 2]:
-                    del self._sliced[k]
-            for b in bursts[(bursts["flags"] & _native.BURST_DEMOD) != 0]:
-                self._sliced[int(b["offset"])] = (b["bits"].copy(), int(b["flags"]))
-        for b, s in zip(bursts, snr):
-            self.add_item_tag(
-                0,
-                int(b["offset"]),
-                pmt.to_pmt("burst"),
-                pmt.to_pmt(("SOB", float(s) if HAVE_GNURADIO else s)),
-                pmt.to_pmt("framer"),
-            )
+        if len(bursts):                                   # (most scheduler-sized work() calls carry no burst)
+            snr = _native.snr_db(bursts["peak"], bursts["median"])
+            if self._paired:
+                dem = (bursts["flags"] & _native.BURST_DEMOD) != 0
+                if dem.any():
+                    self._slices.put(bursts["offset"][dem], bursts["bits"][dem], bursts["flags"][dem])
+            # one tag per burst is the only per-burst work the API forces (framer.py:168-174); everything else is arrays.
+            # real pmt.to_pmt wants Python floats; under the stand-in runtime the value stays np.float32 like the reference's
+            key, src, add, to_pmt = self._pmt_key, self._pmt_src, self.add_item_tag, pmt.to_pmt
+            for off, s in zip(bursts["offset"].tolist(), snr.tolist() if HAVE_GNURADIO else list(snr)):
+                add(0, off, key, to_pmt(("SOB", s)), src)
         _passthrough(self._ctx, out0, in0[self.N_hist - 1:])
         return N
 
@@ -221,11 +279,15 @@ class demod(gr.sync_block):
         self._framer = framer
         if framer is not None and (framer.improved or self.improved):
             raise ValueError("framer= pairing is for the reference-exact blocks (improved=False on both)")
+        if framer is not None:
+            framer._paired = True
+        self.device_calls = 0             # work() calls that went to the device (paired mode: only the fall-back)
         self.want_confidence = framer is None  # demod.py:101 computes it on every burst
         self.set_tag_propagation_policy(gr.TPP_ONE_TO_ONE)
         if min_chunk:
             self.set_output_multiple(int(min_chunk))
-        self.message_port_register_out(pmt.to_pmt("demodulated"))
+        self._pmt_port, self._pmt_key = pmt.to_pmt("demodulated"), pmt.to_pmt("burst")
+        self.message_port_register_out(self._pmt_port)
         self._ctx = _native.Context(fs, 0.0, device=device)
 
     def work(self, input_items, output_items):
@@ -234,47 +296,47 @@ class demod(gr.sync_block):
         if self.straddled_packet == 1:
             self.straddled_packet = 0
         nread = self.nitems_read(0)
-        tags = self.get_tags_in_range(0, nread, nread + len(in0), pmt.to_pmt("burst"))
+        tags = self.get_tags_in_range(0, nread, nread + len(in0), self._pmt_key)
         if self.improved:
             self._work_improved(in0, nread, tags)
         elif len(tags):
-            offs = np.array([t.offset for t in tags], dtype=np.int64)
-            sliced = None
+            offs = np.fromiter((t.offset for t in tags), dtype=np.int64, count=len(tags))
+            bits = None
             if self._framer is not None and not self.want_confidence:
                 # bits the paired framer's pass already holds; this block's own drop rule (demod.py:76,82)
                 end = self.nitems_written(0) + len(in0)
-                fits = offs + 119 * self.sps + self.sps // 2 < end
-                got = [self._framer._sliced.pop(int(o), None) for o in offs]
-                if all((g is not None) or (not f) for g, f in zip(got, fits)):
-                    sliced = got
-            if sliced is not None:
-                ok = fits
-                bits = np.zeros((len(offs), 112), dtype=np.uint8)
-                pf = np.zeros(len(offs), dtype=np.uint8)
-                for i, g in enumerate(sliced):
-                    if ok[i]:
-                        bits[i] = np.unpackbits(g[0])[:112]
-                        pf[i] = g[1] & 0xFF
-                ratio = None
-            else:
+                ok = offs + (119 * self.sps + self.sps // 2) < end
+                found, b14, pf = self._framer._slices.take(offs)
+                if bool((found | ~ok).all()):
+                    bits = np.unpackbits(b14, axis=1)[:, :112]       # ONE call for the whole chunk
+                    ratio = None
+            if bits is None:
                 # demod.py:79 indexes with nitems_written(0); equal to nitems_read(0) for this sync block
                 bits, ok, ratio = self._ctx.demod_work(in0, self.nitems_written(0), offs, want_ratio=self.want_confidence)
                 pf = self._ctx.last_demod_flags
-            for i, tag in enumerate(tags):
-                if not ok[i]:
-                    self.straddled_packet = 1     # demod.py:130-133: dropped
-                    continue
-                if self.parity_filter and not _prefilter_pass(int(pf[i]), int(bits[i][:5] @ _DF_WEIGHTS)):
-                    self.filtered += 1
-                    continue
-                value = pmt.to_python(tag.value)
-                snr = value[1]
-                self.bits = bits[i].copy()
+                self.device_calls += 1
+            # one PDU per burst is the only per-burst work the API forces (demod.py:104-110)
+            ts0, fs, port, pub = self.start_timestamp, self.fs, self._pmt_port, self.message_port_pub
+            to_pmt, to_python, cons = pmt.to_pmt, pmt.to_python, pmt.cons
+            if ratio is None and not self.parity_filter and bool(ok.all()):
+                for i, tag in enumerate(tags):
+                    pub(port, cons(to_pmt({"timestamp": ts0 + tag.offset / fs, "snr": to_python(tag.value)[1]}), to_pmt(bits[i])))
+                self.bits = bits[-1]                  # demod.py:95 keeps the last burst's bits on the block
+            else:
                 if ratio is not None:
                     with np.errstate(all="ignore"):
-                        self.bit_confidence = np.float32(10.0) * np.log10(ratio[i])
-                self.message_port_pub(pmt.to_pmt("demodulated"),
-                                      make_pdu(self.start_timestamp, self.fs, tag.offset, snr, self.bits))
+                        conf = np.float32(10.0) * np.log10(ratio)      # demod.py:101, the whole chunk at once
+                for i, tag in enumerate(tags):
+                    if not ok[i]:
+                        self.straddled_packet = 1     # demod.py:130-133: dropped
+                        continue
+                    if self.parity_filter and not _prefilter_pass(int(pf[i]), int(bits[i][:5] @ _DF_WEIGHTS)):
+                        self.filtered += 1
+                        continue
+                    self.bits = bits[i]
+                    if ratio is not None:
+                        self.bit_confidence = conf[i]                   # as it stands when this PDU is published
+                    pub(port, cons(to_pmt({"timestamp": ts0 + tag.offset / fs, "snr": to_python(tag.value)[1]}), to_pmt(bits[i])))
         _passthrough(self._ctx, out0, in0)
         return len(out0)
 

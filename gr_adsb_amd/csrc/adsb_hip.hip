@@ -758,7 +758,7 @@ int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx
   *out = nullptr;
   if (!(fs > 0) || fmod(fs, 1e6) != 0.0) return -EINVAL;        // framer.py:44, demod.py:42
   long long sps = (long long)(fs / 1e6);
-  if (sps < 2 || (sps & 1) || sps > 4096) return -EINVAL;        // odd sps crashes the reference's work()
+  if (sps < 2 || (sps & 1) || sps > ADSB_MAX_SPS) return -EINVAL;   // odd sps crashes the reference's work(); above the maximum: untested
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -ENODEV;   // no CPU fallback, by design
   if (device < 0 || device >= ndev) return -ENODEV;

@@ -4,6 +4,9 @@ constructed and driven work()-call by work()-call exactly the way the scheduler'
 would (SURVEY.md §8b B2 lists the surface).  Not a scheduler: drive() below calls work() with an
 explicit chunk schedule.
 """
+import bisect
+import queue
+import threading
 import types
 
 import numpy as np
@@ -58,13 +61,22 @@ class sync_block:
         self.tags_out.append(Tag(offset, key, value, srcid))
 
     def get_tags_in_range(self, port, start, end, key=None):
-        return [t for t in self.tags_in if start <= t.offset < end and (key is None or t.key == key)]
+        # tags arrive in stream order (one upstream block appends them): a bisection instead of a scan of the whole list
+        tin = self.tags_in
+        n = len(tin)                          # (a threaded driver appends while this runs: only the first n are looked at)
+        lo = bisect.bisect_left(tin, start, 0, n, key=_tag_offset)
+        hi = bisect.bisect_left(tin, end, lo, n, key=_tag_offset)
+        return [t for t in tin[lo:hi] if key is None or t.key == key]
 
     def message_port_register_out(self, name):
         self._ports.append(name)
 
     def message_port_pub(self, port, msg):
         self.messages.append((port, msg))
+
+
+def _tag_offset(t):
+    return t.offset
 
 
 pmt = types.SimpleNamespace(
@@ -100,4 +112,62 @@ def drive(framer_blk, demod_blk, x, schedule=None, demod_schedule=None):
         demod_blk._nread = demod_blk._nwritten = pos
         demod_blk.work([y[pos:pos + N]], [out0])
         pos += N
+    return framer_blk.tags_out, demod_blk.messages
+
+
+def drive_threaded(framer_blk, demod_blk, x, schedule, demod_lag=0, depth=4):
+    """The two blocks the way GNU Radio's thread-per-block scheduler runs them: the framer's work() calls on one thread,
+    the demod's on another, a bounded buffer of `depth` chunks between them (the scheduler's ring buffer), the demod
+    seeing the framer's tags live (the same list, appended to while it is read).  demod_lag > 0: the demod does not
+    start before the framer has finished that many calls (then `depth` grows to hold them) -- a demod that lags, which is
+    when a paired demod finds the framer's slices forgotten and falls back to the device.  Both blocks get the same
+    chunking, like a real sync-block chain.  Returns (tags, messages); an exception on either thread is re-raised."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    L = len(x)
+    schedule = list(schedule)
+    assert sum(schedule) == L
+    H = framer_blk.history()
+    buf = np.concatenate([np.zeros(H - 1, dtype=np.float32), x])
+    y = np.empty(L, dtype=np.float32)
+    q = queue.Queue(maxsize=max(depth, demod_lag + 1))
+    started = threading.Event()
+    errors = []
+    demod_blk.tags_in = framer_blk.tags_out              # live: what TPP_ONE_TO_ONE propagation gives the demod
+
+    def run_framer():
+        try:
+            pos = 0
+            for k, N in enumerate(schedule):
+                framer_blk._nread = framer_blk._nwritten = pos
+                assert framer_blk.work([buf[pos:pos + N + H - 1]], [y[pos:pos + N]]) == N
+                q.put((pos, N))
+                pos += N
+                if k + 1 >= demod_lag:
+                    started.set()
+        except BaseException as e:          # noqa: BLE001 - handed to the caller
+            errors.append(e)
+        finally:
+            started.set()
+            q.put(None)
+
+    def run_demod():
+        try:
+            started.wait()
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                pos, N = item
+                demod_blk._nread = demod_blk._nwritten = pos
+                demod_blk.work([y[pos:pos + N]], [np.empty(N, dtype=np.float32)])
+        except BaseException as e:          # noqa: BLE001
+            errors.append(e)
+            while q.get() is not None:      # let the framer finish
+                pass
+
+    tf, td = threading.Thread(target=run_framer), threading.Thread(target=run_demod)
+    tf.start(); td.start()
+    tf.join(); td.join()
+    if errors:
+        raise errors[0]
     return framer_blk.tags_out, demod_blk.messages

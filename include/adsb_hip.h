@@ -34,6 +34,7 @@ extern "C" {
 #endif
 
 #define ADSB_ABI_VERSION 2
+#define ADSB_MAX_SPS 100 /* highest sample rate accepted: 100 Msps (tested up to and including it against the reference) */
 #ifndef ADSB_MAX_IN_FLIGHT
 #define ADSB_MAX_IN_FLIGHT 3 /* adsb_submit_* calls that may be pending at once */
 #endif
@@ -120,7 +121,11 @@ typedef struct adsb_stats {
 int adsb_abi_version(void);
 
 /* fs must be an even multiple of 1e6 (the reference asserts fs % 1e6 == 0, framer.py:44, and only
- * works for even sps): otherwise -EINVAL.  device = HIP ordinal. */
+ * works for even sps) between 2e6 and ADSB_MAX_SPS * 1e6: otherwise -EINVAL.  2 / 4 / 8 / 20 Msps run
+ * kernels with the preamble tap stride (sps / 2, framer.py:137) compiled in, every other rate ("2 Msps, 4 Msps, 6 Msps,
+ * etc", README.md:17) the run-time-stride instances; all are pinned by reference vectors (tests/golden/R*.npz: 6, 10, 12,
+ * 16, 24, 40 and 100 Msps).  The reference itself has no upper limit; above 100 Msps nothing is tested, so nothing is
+ * accepted.  device = HIP ordinal. */
 int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx** out);
 void adsb_destroy(adsb_ctx* ctx);
 int adsb_set_threshold(adsb_ctx* ctx, float threshold);

@@ -24,6 +24,17 @@ def large_golden_names():
     return _names("L*.npz")
 
 
+def rate_golden_names():
+    """Round-4 vectors (tools/make_golden_lcg.py): the rates beyond the four instantiated ones -- 6 / 10 / 12 / 16 / 24 / 40 /
+    100 Msps, served by the run-time-stride kernels.  Input = tests/lcg_stream.py (code), outputs = the reference's."""
+    return _names("R*.npz")
+
+
+def bulk_golden_names():
+    """Round-4 vector: 2^28 samples at 2 Msps (generated, never stored) + the reference's tags and PDUs for them."""
+    return _names("B*.npz")
+
+
 def pathological_names():
     """Round-3 vectors: float32 |IQ|^2 with NaN / inf, thresholds <= 0, multi-tile plateaus, ties, tiny inputs."""
     return _names("P*.npz")
@@ -35,14 +46,22 @@ def schedules_of(name):
 
 
 class Golden:
-    def __init__(self, name):
+    def __init__(self, name, lazy=False):
         z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
         self.name = name
         self.fs = float(z["fs"])
         self.sps = int(self.fs // 1e6)
         self.thr = float(z["threshold"])
         self.iq = self.iq8 = None
-        if "iq16" in z.files:
+        self.gen = None
+        if "gen_n" in z.files:
+            # input is code (tests/lcg_stream.py): the int8 IQ bytes the reference saw are regenerated, not stored
+            import lcg_stream
+            self.gen = {k: int(z["gen_" + k]) for k in lcg_stream.PARAM_KEYS}
+            self.scale = np.float32(z["scale"])
+            if not lazy:
+                self.load_generated()
+        elif "iq16" in z.files:
             self.iq = M.dequantize_iq16(z["iq16"])
             self.x = M.mag2(self.iq)
         elif "iq8" in z.files:
@@ -55,6 +74,15 @@ class Golden:
         else:
             self.x = z["x"]
         self.z = z
+
+    def load_generated(self, lo=0, hi=None):
+        """(Re)generate samples [lo, hi) of a code-backed vector: iq8 bytes, complex64 IQ and |IQ|^2 exactly as the
+        reference saw them (component = f32(int8) * scale, one rounded multiply)."""
+        import lcg_stream
+        self.iq8 = lcg_stream.stream(self.gen, lo=lo, hi=hi)
+        v = self.iq8.astype(np.float32) * self.scale
+        self.iq = (v[0::2] + 1j * v[1::2]).astype(np.complex64)
+        self.x = M.mag2(self.iq)
 
     def sched(self, s):
         return [int(v) for v in self.z[s + "_schedule"]]

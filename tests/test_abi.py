@@ -57,7 +57,8 @@ def test_no_cpu_fallback_without_device(native):
 def test_create_rejects_bad_sample_rates(native):
     lib = native.load()
     h = ctypes.c_void_p()
-    for fs in (2.5e6, 0.0, -2e6, 1e6, 3e6):      # non-integer sps (framer.py:44) / odd sps (work() would raise)
+    # non-integer sps (framer.py:44) / odd sps (work() would raise) / above ADSB_MAX_SPS (nothing beyond it is tested)
+    for fs in (2.5e6, 0.0, -2e6, 1e6, 3e6, 102e6, 4096e6):
         assert lib.adsb_create(fs, 0.01, 0, 0, ctypes.byref(h)) == -22
         assert not h.value
 

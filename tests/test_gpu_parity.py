@@ -6,8 +6,8 @@ import warnings
 import numpy as np
 import pytest
 
-from helpers import (SCHEDULES, Golden, assert_recs_equal, assert_recs_match_golden, golden_names, large_golden_names,
-                     pathological_names, schedules_of, snr_bits, unpack)
+from helpers import (SCHEDULES, Golden, assert_recs_equal, assert_recs_match_golden, bulk_golden_names, golden_names,
+                     large_golden_names, pathological_names, rate_golden_names, schedules_of, snr_bits, unpack)
 
 pytestmark = pytest.mark.gpu
 
@@ -42,13 +42,15 @@ def test_canonical_host_iq_matches_reference_goldens(native, name):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", large_golden_names())
+@pytest.mark.parametrize("name", large_golden_names() + rate_golden_names())
 def test_large_reference_goldens_every_entry_point(native, torch_mod, name):
     """tests/golden/L*.npz (round 3): 2^20 .. 3*2^20 samples per rate, >= 500 reference tags each (20 Msps included), stored as
     int8 IQ -- so the reference's own outputs pin the cs8 entry point (the bytes as they are), the complex64 and the
-    |IQ|^2 entry points (the oracle's exact conversion of the same bytes), host, device-resident, submitted and host-fed."""
+    |IQ|^2 entry points (the oracle's exact conversion of the same bytes), host, device-resident, submitted and host-fed.
+    tests/golden/R*.npz (round 4): the same at 6 / 10 / 12 / 16 / 24 / 40 / 100 Msps -- the run-time-stride instances
+    k_detect<fmt, 0> of three input formats (int8, complex64, |IQ|^2); int16 and uint8 in test_run_time_stride_other_formats."""
     g = Golden(name)
-    assert len(g.get("single", "tag_offsets")) >= 490
+    assert len(g.get("single", "tag_offsets")) >= (490 if name.startswith("L") else 200)
     ctx = native.Context(g.fs, g.thr)
     ctx.set_format_scale(native.FMT_SC8, float(g.scale))
     n = len(g.x)
@@ -84,12 +86,79 @@ def _drive_blocks_vs_golden(g, sched, improved=False):
     assert np.float32(fr.prev_in0).view(np.uint32) == g.get(sched, "final_prev_in0_bits")
 
 
-@pytest.mark.parametrize("name", large_golden_names())
-@pytest.mark.parametrize("sched", ["fixed2048", "random"])
+@pytest.mark.parametrize("name", large_golden_names() + rate_golden_names())
+@pytest.mark.parametrize("sched", ["fixed2048", "random", "randombig"])
 def test_dropin_blocks_match_large_reference_goldens(native, name, sched):
     """The drop-in blocks, work() call by work() call, against the reference under the deaf-state schedule (fixed 2048,
-    framer.py:177-179) and a random 1000-9000 schedule over megasample streams."""
+    framer.py:177-179) and a random 1000-9000 schedule over megasample streams; the rate goldens (R*: k_pass_small<0> for
+    calls of up to four units, k_detect<1, 0> + k_tail_small beyond) also under chunks of 150-1500 symbols."""
+    if sched not in schedules_of(name):
+        pytest.skip("schedule not stored for this vector")
     _drive_blocks_vs_golden(Golden(name), sched)
+
+
+@pytest.mark.parametrize("name", rate_golden_names())
+def test_run_time_stride_other_formats(native, torch_mod, name):
+    """k_detect<int16, 0> and k_detect<uint8, 0> at the rate goldens' rates: the int8 bytes of the vector re-expressed exactly
+    in the other two integer wire formats (int16 = the same integers; offset binary u8 = (v + 255) / 2 for odd v, so v is
+    made odd first and the reference side is the C oracle on the oracle's conversion of those bytes), plus the paired
+    blocks and the stand-alone demod under the stored random schedule."""
+    from oracle import adsb_oracle as O
+    from oracle import c_oracle as C
+    from gr_adsb_amd import blocks, grshim
+    g = Golden(name)
+    ctx = native.Context(g.fs, g.thr)
+    ctx.set_format_scale(native.FMT_SC16, float(g.scale))
+    assert_recs_match_golden(ctx.process_format(native.FMT_SC16, g.iq8.astype(np.int16)), g)
+    u8 = ((g.iq8.astype(np.int16) | 1) + 255) // 2                     # 2*u8 - 255 = v | 1
+    u8 = u8.astype(np.uint8)
+    s8 = float(np.float32(g.scale))
+    ctx.set_format_scale(native.FMT_CU8, s8)
+    want = C.canonical(O.mag2_iq8(u8, s8, True), g.sps, np.float32(g.thr))
+    assert len(want) >= 100
+    assert_recs_equal(ctx.process_format(native.FMT_CU8, u8), want, name + " cu8")
+    ctx.close()
+    fr = blocks.framer(g.fs, g.thr)
+    dm = blocks.demod(g.fs, framer=fr)
+    dm.start_timestamp = 0.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tags, msgs = grshim.drive(fr, dm, g.x, g.sched("randombig"))
+    assert np.array_equal(np.array([t.offset for t in tags], dtype=np.int64), g.get("randombig", "tag_offsets"))
+    assert np.array_equal(np.array([m[1] for _, m in msgs], dtype=np.uint8).reshape(-1, 112), g.pdu_bits("randombig"))
+
+
+@pytest.mark.parametrize("name", bulk_golden_names())
+def test_bulk_reference_golden(native, torch_mod, name):
+    """tests/golden/B*.npz (round 4): 2^28 samples at 2 Msps, generated on the device by tests/lcg_stream.py (the same integer
+    hashing the build container ran in NumPy: identical bytes), against what the UNMODIFIED reference produced for them
+    in one work() call -- 32 k tags and PDUs.  This is the size at which a pass runs as eight resident rounds of short
+    chunks (adsb_plan.h) and the usual-tile instance (EASY) carries all but the first and last tiles: the bulk device path
+    itself pinned by the reference, through the int8, complex64 and |IQ|^2 entry points."""
+    import lcg_stream
+    torch = torch_mod
+    g = Golden(name, lazy=True)
+    n = g.gen["n"]
+    assert n >= 1 << 28
+    iq8 = lcg_stream.stream(g.gen, device="cuda:0")
+    head = lcg_stream.stream(g.gen, lo=0, hi=1 << 16)                  # the NumPy generator and the device one agree
+    assert np.array_equal(iq8[:2 << 16].cpu().numpy(), head)
+    ctx = native.Context(g.fs, g.thr)
+    ctx.set_format_scale(native.FMT_SC8, float(g.scale))
+    assert_recs_match_golden(ctx.process_format_device(native.FMT_SC8, iq8.data_ptr(), n), g)
+    st = ctx.stats()
+    resident = torch.cuda.get_device_properties(0).multi_processor_count * st["blocks_per_cu"] * 4
+    units, per = native.plan_chunks(n, resident)
+    assert units == st["detect_grid"] * 4 or units + 3 >= st["detect_grid"] * 4
+    assert units * per >= n and units >= 4 * resident, "a bulk pass: several resident rounds of short chunks"
+    v = iq8.to(torch.float32) * float(g.scale)                         # f32(int8) * scale: one rounded multiply
+    iq = v.view(n, 2).contiguous()
+    assert_recs_match_golden(ctx.process_iq_device(iq.data_ptr(), n), g)
+    prod = iq * iq                                                     # two rounded products, one rounded add
+    x = (prod[:, 0] + prod[:, 1]).contiguous()
+    del v, prod, iq
+    assert_recs_match_golden(ctx.process_mag2_device(x.data_ptr(), n), g)
+    ctx.close()
 
 
 @pytest.mark.parametrize("name", pathological_names())
@@ -238,6 +307,73 @@ def test_paired_demod_publishes_the_framers_slices(native, name):
             _, msgs = grshim.drive(fr, dm, g.x, fs_, ds_)
             out.append([(int(round(m[0]["timestamp"] * g.fs)), bytes(m[1]), np.float32(m[0]["snr"]).tobytes()) for _, m in msgs])
         assert out[0] == out[1] and len(out[0]) >= 1
+
+
+def _msgs_vs_golden(g, sched, tags, msgs):
+    assert np.array_equal(np.array([t.offset for t in tags], dtype=np.int64), g.get(sched, "tag_offsets"))
+    offs = np.array([int(round(m[0]["timestamp"] * g.fs)) for _, m in msgs], dtype=np.int64)
+    assert np.array_equal(offs, g.get(sched, "pdu_offsets"))
+    assert np.array_equal(np.array([m[1] for _, m in msgs], dtype=np.uint8).reshape(-1, 112), g.pdu_bits(sched))
+    psnr = np.array([m[0]["snr"] for _, m in msgs], dtype=np.float32)
+    assert np.array_equal(psnr.view(np.uint32), g.get(sched, "pdu_snr_bits"))
+
+
+@pytest.mark.parametrize("name", ["L2msps_df17", "L8msps_dense", "R6msps"])
+@pytest.mark.parametrize("sched", ["fixed2048", "random"])
+def test_paired_blocks_on_two_threads(native, name, sched):
+    """The paired blocks the way GNU Radio's thread-per-block scheduler runs them (grshim.drive_threaded: framer.work on one
+    thread, demod.work on another, a bounded buffer between them, the demod reading the framer's tag list while it grows):
+    the framer -> demod slice hand-over (blocks._SliceStore) is shared state of two threads.  Tags and PDUs must equal the
+    reference's under the same schedule -- (1) demod right behind the framer: every PDU comes from the framer's slices, the
+    demod never goes to the device; (2) demod lagging 300 calls behind a store that keeps only 40 bursts: slices are
+    forgotten before they are collected and the demod's device fall-back produces those PDUs -- still the reference's."""
+    from gr_adsb_amd import blocks, grshim
+    g = Golden(name)
+    for lag, cap in ((0, None), (300, 40)):
+        fr = blocks.framer(g.fs, g.thr)
+        dm = blocks.demod(g.fs, framer=fr)
+        dm.start_timestamp = 0.0
+        if cap:
+            fr._slices.cap = cap
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tags, msgs = grshim.drive_threaded(fr, dm, g.x, g.sched(sched), demod_lag=lag)
+        _msgs_vs_golden(g, sched, tags, msgs)
+        assert len(msgs) >= 100
+        if cap:
+            assert fr._slices.evicted > 100 and dm.device_calls > 10, (fr._slices.evicted, dm.device_calls)
+        else:
+            assert fr._slices.evicted == 0 and dm.device_calls == 0
+
+
+def test_paired_blocks_chunk_with_more_bursts_than_the_store_keeps(native, torch_mod):
+    """One work() call of 2^25 samples carrying 16 k bursts -- more than the slice store's capacity (set to 8192 here): the
+    newest call's slices are never forgotten, however many, so every PDU of the chunk still comes from the framer's pass;
+    and with the store emptied behind the framer's back (a demod that was disconnected for a while) the device fall-back
+    delivers the same PDUs.  Checked against the NumPy oracle (pinned to the reference, tests/test_oracle_vs_reference.py)."""
+    import lcg_stream
+    from gr_adsb_amd import blocks, grshim
+    from oracle import adsb_oracle as O
+    p = lcg_stream.params(1 << 25, 2, 77, 2048)
+    iq8 = lcg_stream.stream(p, device="cuda:0").cpu().numpy()
+    scale = np.float32(1.0 / 128.0)
+    x = O.mag2_iq8(iq8, float(scale), False)
+    sched = [1 << 25]
+    o = O.run_stream(x, 2e6, 0.005, sched)
+    assert len(o["pdu_offsets"]) > 12000
+    for sabotage in (False, True):
+        fr = blocks.framer(2e6, 0.005)
+        dm = blocks.demod(2e6, framer=fr)
+        dm.start_timestamp = 0.0
+        fr._slices.cap = 8192
+        if sabotage:
+            fr._slices.put = lambda *a: None                      # nothing is ever stored: every chunk takes the fall-back
+        tags, msgs = grshim.drive(fr, dm, x, sched)
+        assert np.array_equal(np.array([t.offset for t in tags], dtype=np.int64), o["tag_offsets"])
+        offs = np.array([int(round(m[0]["timestamp"] * 2e6)) for _, m in msgs], dtype=np.int64)
+        assert np.array_equal(offs, o["pdu_offsets"])
+        assert np.array_equal(np.array([m[1] for _, m in msgs], dtype=np.uint8).reshape(-1, 112), o["pdu_bits"])
+        assert dm.device_calls == (1 if sabotage else 0) and fr._slices.evicted == 0
 
 
 @pytest.mark.parametrize("name", golden_names())

@@ -5,8 +5,8 @@ import os
 import numpy as np
 import pytest
 
-from helpers import (GOLDEN_DIR, SCHEDULES, Golden, golden_names, large_golden_names, pathological_names, schedules_of,
-                     snr_bits, unpack)
+from helpers import (GOLDEN_DIR, SCHEDULES, Golden, bulk_golden_names, golden_names, large_golden_names, pathological_names,
+                     rate_golden_names, schedules_of, snr_bits, unpack)
 from oracle import adsb_oracle as O
 from oracle import c_oracle as C
 
@@ -70,6 +70,49 @@ def test_oracles_match_large_reference_goldens(name):
     _c_oracle_vs(g)
     if g.iq8 is not None:                              # the C port's own int8 conversion on the same bytes
         assert np.array_equal(O.mag2_iq8(g.iq8, float(g.scale), False), g.x)
+
+
+@pytest.mark.parametrize("name", rate_golden_names())
+def test_oracles_match_rate_reference_goldens(name):
+    """tests/golden/R*.npz (round 4): 6 / 10 / 12 / 16 / 24 / 40 / 100 Msps -- the rates the reference advertises beyond the
+    four instantiated ones (README.md:17, framer.py:45,137) -- single call, deaf-state and two random schedules.  The
+    input is regenerated from tests/lcg_stream.py."""
+    g = Golden(name)
+    assert g.sps not in (2, 4, 8, 20) and len(g.get("single", "tag_offsets")) >= 200
+    for sched in schedules_of(name):
+        _numpy_oracle_vs(g, sched)
+    _c_oracle_vs(g)
+    assert np.array_equal(O.mag2_iq8(g.iq8, float(g.scale), False), g.x)
+
+
+@pytest.mark.parametrize("name", bulk_golden_names())
+def test_c_oracle_matches_bulk_reference_golden_on_a_prefix(name):
+    """tests/golden/B*.npz: the reference's tags for 2^28 generated samples.  Here (CPU) the first 2^23 samples are
+    regenerated and the C oracle must reproduce every reference tag whose burst lies inside them (the gate is causal; only
+    the PDU drop rule at the end of a call depends on the call's length, demod.py:82); the GPU test runs all 2^28."""
+    g = Golden(name, lazy=True)
+    n = 1 << 23
+    g.load_generated(0, n)
+    r = C.canonical(g.x, g.sps, np.float32(g.thr))
+    offs = g.get("single", "tag_offsets")
+    k = int(np.searchsorted(offs, n - 8 * g.sps + 1))            # tags the prefix call can see: centre < n - (H - 1)
+    assert k > 500 and np.array_equal(r["offset"], offs[:k])
+    assert np.array_equal(snr_bits(r["peak"], r["median"]), g.get("single", "tag_snr_bits")[:k])
+    dem = (r["flags"] & 1) != 0
+    kp = int(dem.sum())
+    assert np.array_equal(r["offset"][dem], g.get("single", "pdu_offsets")[:kp])
+    assert np.array_equal(unpack(r["bits"][dem]), g.pdu_bits("single")[:kp])
+
+
+def test_generated_streams_are_identical_under_numpy_and_torch():
+    """tests/lcg_stream.py: integer hashing only -- the NumPy path (what the reference was run on) and the torch path
+    (what the GPU box generates on the device) must give the same bytes, and any window stands on its own."""
+    import lcg_stream as L
+    for sps, gap in ((2, 4000), (6, 1000), (100, 16000)):
+        p = L.params(1 << 17, sps, 17 + sps, gap)
+        a = L.stream(p, block=1 << 15)
+        assert np.array_equal(a, L.stream(p, device="cpu", block=50000).numpy())
+        assert np.array_equal(L.stream(p, lo=12345, hi=99999), a[2 * 12345:2 * 99999])
 
 
 @pytest.mark.parametrize("name", pathological_names())

@@ -31,7 +31,8 @@ def _same(r, o):
     assert np.float32(r["final_prev_in0"]).view(np.uint32) == np.float32(o["final_prev_in0"]).view(np.uint32)
 
 
-@pytest.mark.parametrize("fs,bps", [(2e6, 2000), (4e6, 3000), (8e6, 6000), (20e6, 3000)])
+@pytest.mark.parametrize("fs,bps", [(2e6, 2000), (4e6, 3000), (8e6, 6000), (20e6, 3000),
+                                    (6e6, 4000), (10e6, 5000), (12e6, 6000), (16e6, 8000), (50e6, 20000), (100e6, 50000)])
 def test_single_and_random_schedules(fs, bps):
     R = _ref()
     rng = np.random.default_rng(int(fs))
@@ -115,7 +116,8 @@ def test_parity_oracle_matches_live_reference_decoder():
 def test_c_oracle_equals_live_reference_on_adversarial_streams():
     """The scalar C port (oracle/adsb_oracle.c) is what the GPU box checks the HIP path against on pathological streams;
     here it meets the UNMODIFIED reference directly on 300 streams from the seam-targeted adversarial generator
-    (plateaus over tile seams, exact ties, NaN, thresholds <= 0 and sitting on sample values, sps 2/4/8/20)."""
+    (plateaus over tile seams, exact ties, NaN, thresholds <= 0 and sitting on sample values; the four instantiated rates
+    and 6 / 10 / 12 / 16 / 30 / 100 Msps, the run-time-stride rates)."""
     import warnings
     from oracle import c_oracle as C
     from helpers import snr_bits, unpack
@@ -127,7 +129,7 @@ def test_c_oracle_equals_live_reference_on_adversarial_streams():
         for seed in range(300):
             rng = np.random.default_rng(7000 + seed)
             n = int(rng.choice([1, 17, 240, 1023, 1024, 1025, 1279, 1280, 1281, 2049, 3333, 4096, 4352, 8193, 12288, 30000]))
-            sps = int(rng.choice([2, 4, 8, 20]))
+            sps = int(rng.choice([2, 4, 8, 20, 6, 10, 12, 16, 30, 100]))
             thr = float(rng.choice([0.01, 0.0099, 0.0101, 0.004, 0.05, 0.0, -1.0]))
             x = adversarial_stream(rng, n, sps)
             if seed % 5 == 0:

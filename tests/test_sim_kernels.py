@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import simlib
-from helpers import Golden, assert_recs_equal, assert_recs_match_golden, golden_names, unpack
+from helpers import Golden, assert_recs_equal, assert_recs_match_golden, golden_names, rate_golden_names, snr_bits, unpack
 from gr_adsb_amd import modulator as M
 from oracle import adsb_oracle as O
 from oracle import c_oracle as C
@@ -22,6 +22,46 @@ def test_canonical_matches_goldens(name, mode):
     assert so.overflow == 0
     assert_recs_match_golden(recs, g)
     assert np.all((recs["flags"] & 2) != 0)
+
+
+@pytest.mark.parametrize("name", rate_golden_names())
+def test_run_time_stride_instances_match_rate_goldens(name):
+    """tests/golden/R*.npz: 6 / 10 / 12 / 16 / 24 / 40 / 100 Msps, the rates served by k_detect<fmt, 0> and k_pass_small<0>
+    (tap stride sps//2 known only at run time, taps bounds-checked against the LDS window; framer.py:45,137).  A prefix of
+    the generated stream through the emulated kernels: canonical int8 / complex64 / |IQ|^2 entry vs the reference's tags
+    (the gate is causal, so the tags of a prefix are a prefix of the tags), and work() call by work() call under the
+    stored random schedule (k_pass_small<0> for the short calls, k_detect<1, 0> + the tail for the long ones)."""
+    g = Golden(name, lazy=True)
+    n = min(g.gen["n"], 60 * 120 * g.sps)                       # room for ~60 back-to-back replies
+    g.load_generated(0, n)
+    offs = g.get("single", "tag_offsets")
+    k = int(np.searchsorted(offs, n - 8 * g.sps + 1))
+    assert k >= 10
+    for mode, data in ((3, g.iq8), (0, g.iq), (1, g.x)):
+        recs, so = simlib.sim_canonical(mode, data, g.fs, g.thr, grid_max=3, **({"scale": float(g.scale)} if mode == 3 else {}))
+        assert so.overflow == 0
+        assert np.array_equal(recs["offset"], offs[:k]), "mode %d" % mode
+        assert np.array_equal(snr_bits(recs["peak"], recs["median"]), g.get("single", "tag_snr_bits")[:k])
+        dem = (recs["flags"] & 1) != 0
+        assert np.array_equal(unpack(recs["bits"][dem]), g.pdu_bits("single")[:int(dem.sum())])
+    sched, pos = [], 0
+    for N in g.sched("random"):
+        if pos + N > n:
+            break
+        sched.append(N)
+        pos += N
+    H = 8 * g.sps
+    buf = np.concatenate([np.zeros(H - 1, np.float32), g.x])
+    fr = simlib.SimFramer(g.fs, g.thr)
+    pos, outs = 0, []
+    for N in sched:
+        outs.append(fr.work(buf[pos:pos + N + H - 1], N, pos)[0])
+        pos += N
+    recs = np.concatenate(outs)
+    want = g.get("random", "tag_offsets")
+    kk = int(np.searchsorted(want, pos - 8 * g.sps + 1))
+    assert kk >= 5 and np.array_equal(recs["offset"], want[:kk])
+    assert np.array_equal(snr_bits(recs["peak"], recs["median"]), g.get("random", "tag_snr_bits")[:kk])
 
 
 @pytest.mark.parametrize("name", golden_names())

@@ -50,7 +50,7 @@ def adversarial_stream(rng, n, sps):
 @settings(max_examples=150, deadline=None, suppress_health_check=list(HealthCheck))
 @given(seed=st.integers(0, 2**31 - 1),
        n=st.sampled_from([1, 17, 240, 1023, 1024, 1025, 1279, 1280, 1281, 2047, 2048, 2049, 3333, 4096, 4352, 8193, 12288]),
-       sps=st.sampled_from([2, 4, 8, 20]),
+       sps=st.sampled_from([2, 4, 8, 20, 6, 10, 12, 16, 30, 100]),    # the four instantiated rates + run-time-stride ones
        thr=st.sampled_from([0.01, 0.0099, 0.0101, 0.004, 0.05, 0.0, -1.0]))
 def test_canonical_equals_c_oracle_on_adversarial_streams(seed, n, sps, thr):
     rng = np.random.default_rng(seed)
@@ -62,7 +62,7 @@ def test_canonical_equals_c_oracle_on_adversarial_streams(seed, n, sps, thr):
 
 
 @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
-@given(seed=st.integers(0, 2**31 - 1), sps=st.sampled_from([2, 8]))
+@given(seed=st.integers(0, 2**31 - 1), sps=st.sampled_from([2, 8, 6, 12, 100]))
 def test_framer_work_random_schedules_equal_numpy_oracle(seed, sps):
     rng = np.random.default_rng(seed)
     n = int(rng.choice([6000, 9000, 13000]))

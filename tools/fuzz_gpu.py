@@ -32,7 +32,7 @@ def main():
     while time.time() - t0 < budget:
         rng = np.random.default_rng(seed)
         n = int(rng.choice(sizes, p=np.array([3] * 20 + [2, 1, 0.5, 0.25]) / (60 + 3.75)))
-        sps = int(rng.choice([2, 4, 8, 20]))
+        sps = int(rng.choice([2, 4, 8, 20, 6, 10, 12, 16, 30, 100]))      # instantiated rates + run-time-stride ones
         thr = float(rng.choice([0.01, 0.0099, 0.0101, 0.004, 0.05]))
         x = adversarial_stream(rng, n, sps)
         ctx = ctxs.setdefault(sps, _native.Context(sps * 1e6, thr))

@@ -811,6 +811,30 @@ def main():
             torch.cuda.empty_cache()
             result["extra_configs"] = extra_configs(args, dev, DEPTH)
             result["formats"] = format_legs(args, dev, DEPTH)
+        # A compact, FLAT copy of every leg's verdict inside `config` (scalars only): a reader that keeps just the headline
+        # keys of the line still sees each config's / format's roofline fraction, time per step and bit-match.
+        cfgd = result["config"]
+        if "bit_match" in result:
+            cfgd["bit_match_identical"] = bool(result["bit_match"]["identical"])
+            cfgd["bit_match_bursts"] = int(result["bit_match"]["sample_bursts"])
+        cfgd["roofline_frac_isolated"] = (result["roofline"].get("isolated") or {}).get("frac")
+        for rec in result.get("extra_configs", []) + result.get("formats", []):
+            key = rec["name"].split("_")[0].replace("config", "cfg") if rec["name"].startswith("config") else rec["format"]
+            cfgd[key + "_frac"] = rec["roofline"]["frac"]
+            cfgd[key + "_ms"] = rec["ms_per_step"]
+            cfgd[key + "_identical"] = bool(rec["bit_match"]["identical"])
+            if "sharded" in rec:
+                cfgd[key + "_8shards_msps"] = rec["sharded"]["value"]
+                cfgd[key + "_stitched_equals_single"] = bool(rec["sharded"]["stitched_equals_single_call"])
+        hf = result.get("host_fed", {}).get("formats", {})
+        for name, rec in hf.items():
+            cfgd["hostfed_%s_pinned_msps" % name] = rec["pinned"]["value"]
+            cfgd["hostfed_%s_pageable_msps" % name] = rec["pageable"]["value"]
+        if n_gpus > 1 and result.get("multi_gpu"):
+            cfgd["seams_identical"] = bool(result["multi_gpu"]["seam_check"]["all_identical"])
+            cfgd["stitch_fallbacks"] = int(result["multi_gpu"]["stitch_fallbacks_total"])
+            if result.get("host_fed", {}).get("total"):
+                cfgd["hostfed_total_msps"] = result["host_fed"]["total"]["value"]
         print(json.dumps(result), flush=True)
     if n_gpus > 1:
         sync_all()

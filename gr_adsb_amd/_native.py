@@ -43,7 +43,7 @@ EXPORTS = [
     "adsb_set_format_scale", "adsb_process_format", "adsb_process_format_device", "adsb_submit_format_device",
     "adsb_submit_format_host", "adsb_last_confidence",
     "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_shard_host", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_mode_s_syndrome", "adsb_plan_chunks", "adsb_get_stats",
-    "adsb_reset_stats", "adsb_last_error", "adsb_host_alloc", "adsb_host_free", "adsb_host_register", "adsb_host_unregister",
+    "adsb_reset_stats", "adsb_detect_history", "adsb_last_error", "adsb_host_alloc", "adsb_host_free", "adsb_host_register", "adsb_host_unregister",
 ]
 
 
@@ -125,6 +125,7 @@ def load():
     lib.adsb_plan_chunks.restype = c.c_int32
     lib.adsb_get_stats.argtypes = [vp, c.POINTER(Stats)]
     lib.adsb_reset_stats.argtypes = [vp]
+    lib.adsb_detect_history.argtypes = [vp, vp, i32, c.POINTER(i32)]
     lib.adsb_host_alloc.argtypes = [c.POINTER(vp), c.c_size_t]
     lib.adsb_host_free.argtypes = [vp]
     lib.adsb_host_register.argtypes = [vp, c.c_size_t]
@@ -378,6 +379,13 @@ class Context:
 
     def reset_stats(self):
         self._chk(self.lib.adsb_reset_stats(self._h))
+
+    def detect_history(self):
+        """Per-launch k_detect durations (ms) since the last reset_stats, oldest first (FLAG_TIMING contexts)."""
+        buf = np.zeros(4096, dtype=np.float32)
+        n = ctypes.c_int32(0)
+        self._chk(self.lib.adsb_detect_history(self._h, ctypes.c_void_p(buf.ctypes.data), len(buf), ctypes.byref(n)))
+        return buf[:n.value].copy()
 
 
 class PinnedArray:

@@ -283,6 +283,10 @@ struct adsb_ctx {
   CopyPool* pool = nullptr;    // host copy threads of the pageable path (adsb_set_copy_threads; created on first use)
   int copy_threads = -1;       // -1 = default
   adsb_stats stats{};
+  // per-launch k_detect durations of the timed calls (ADSB_FLAG_TIMING), a ring of the last kHist: adsb_detect_history
+  static constexpr int kHist = 4096;
+  std::vector<float> det_hist;
+  uint64_t det_hist_n = 0;
   char err[256] = {0};
 };
 
@@ -545,6 +549,8 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
       FINCHK(hipEventElapsedTime(&ms, s.ev0, s.ev1));
       c->stats.detect_launches++;
       c->stats.detect_ms += ms;
+      if (c->det_hist.size() < (size_t)adsb_ctx::kHist) c->det_hist.resize(adsb_ctx::kHist);
+      c->det_hist[c->det_hist_n++ % adsb_ctx::kHist] = ms;
       // idle time on the compute stream between the previous pass's k_detect and this one (pipelined use)
       // idle time on the compute stream between this pass's k_detect and the NEXT pass's (already queued in
       // pipelined use; its events are valid if that pass has been collected or is complete -- best effort)
@@ -1290,6 +1296,16 @@ int adsb_get_stats(adsb_ctx* c, adsb_stats* out) {
 int adsb_reset_stats(adsb_ctx* c) {
   if (!c) return -EINVAL;
   memset(&c->stats, 0, sizeof(c->stats));
+  c->det_hist_n = 0;
+  return 0;
+}
+
+int adsb_detect_history(adsb_ctx* c, float* ms, int32_t cap, int32_t* n) {
+  if (!c || cap < 0 || (cap > 0 && !ms) || !n) return -EINVAL;
+  const uint64_t have = c->det_hist_n < (uint64_t)adsb_ctx::kHist ? c->det_hist_n : (uint64_t)adsb_ctx::kHist;
+  const uint64_t take = have < (uint64_t)cap ? have : (uint64_t)cap;
+  for (uint64_t i = 0; i < take; ++i) ms[i] = c->det_hist[(c->det_hist_n - take + i) % adsb_ctx::kHist];   // oldest first
+  *n = (int32_t)take;
   return 0;
 }
 

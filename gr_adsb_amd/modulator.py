@@ -93,7 +93,8 @@ def synth_iq(n, fs, bursts_per_s, seed, noise_power=1e-3, amp2_range=(0.05, 1.0)
         else:
             p = rng.uniform(*amp2_range)
         ph = rng.uniform(0, 2 * np.pi)
-        z[s:s + len(env)] += (np.float32(np.sqrt(p)) * env * np.complex64(np.exp(1j * ph))).astype(np.complex64)
+        m = min(len(env), n - s)                    # (a stream shorter than one reply: the burst is cut by its end)
+        z[s:s + m] += (np.float32(np.sqrt(p)) * env[:m] * np.complex64(np.exp(1j * ph))).astype(np.complex64)
         truth.append((int(s), int(df), bits))
     if return_truth:
         return z, truth

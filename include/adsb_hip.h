@@ -294,6 +294,11 @@ int32_t adsb_plan_chunks(int64_t n_samples, int64_t resident_wavefronts, int64_t
 
 int adsb_get_stats(adsb_ctx* ctx, adsb_stats* out);
 int adsb_reset_stats(adsb_ctx* ctx);
+/* The duration (ms, HIP events on the compute stream) of every k_detect launch the context has timed since the last
+ * adsb_reset_stats, oldest first -- the last 4096 of them; contexts created with ADSB_FLAG_TIMING only.  adsb_stats holds
+ * their sum; this is the per-launch sequence (measurement aid: tools/launch_hist.py holds it against a rocprofv3 kernel
+ * trace launch by launch).  No reference counterpart.  *n = durations written (<= cap). */
+int adsb_detect_history(adsb_ctx* ctx, float* ms, int32_t cap, int32_t* n);
 /* Text of the last error on this context ("" if none). */
 const char* adsb_last_error(adsb_ctx* ctx);
 

@@ -153,10 +153,12 @@ def test_bulk_reference_golden(native, torch_mod, name):
     assert units * per >= n and units >= 4 * resident, "a bulk pass: several resident rounds of short chunks"
     v = iq8.to(torch.float32) * float(g.scale)                         # f32(int8) * scale: one rounded multiply
     iq = v.view(n, 2).contiguous()
+    torch.cuda.synchronize()                                           # (the context runs on its own stream)
     assert_recs_match_golden(ctx.process_iq_device(iq.data_ptr(), n), g)
     prod = iq * iq                                                     # two rounded products, one rounded add
     x = (prod[:, 0] + prod[:, 1]).contiguous()
     del v, prod, iq
+    torch.cuda.synchronize()
     assert_recs_match_golden(ctx.process_mag2_device(x.data_ptr(), n), g)
     ctx.close()
 
@@ -325,11 +327,12 @@ def test_paired_blocks_on_two_threads(native, name, sched):
     thread, demod.work on another, a bounded buffer between them, the demod reading the framer's tag list while it grows):
     the framer -> demod slice hand-over (blocks._SliceStore) is shared state of two threads.  Tags and PDUs must equal the
     reference's under the same schedule -- (1) demod right behind the framer: every PDU comes from the framer's slices, the
-    demod never goes to the device; (2) demod lagging 300 calls behind a store that keeps only 40 bursts: slices are
+    demod never goes to the device; (2) demod lagging 300 calls behind a store that keeps only 20 bursts: slices are
     forgotten before they are collected and the demod's device fall-back produces those PDUs -- still the reference's."""
     from gr_adsb_amd import blocks, grshim
     g = Golden(name)
-    for lag, cap in ((0, None), (300, 40)):
+    many = len(g.get(sched, "pdu_offsets")) >= 200      # (8 Msps in 2048-sample calls: nearly every burst is dropped)
+    for lag, cap in ((0, None), (300, 20)):
         fr = blocks.framer(g.fs, g.thr)
         dm = blocks.demod(g.fs, framer=fr)
         dm.start_timestamp = 0.0
@@ -339,10 +342,10 @@ def test_paired_blocks_on_two_threads(native, name, sched):
             warnings.simplefilter("ignore")
             tags, msgs = grshim.drive_threaded(fr, dm, g.x, g.sched(sched), demod_lag=lag)
         _msgs_vs_golden(g, sched, tags, msgs)
-        assert len(msgs) >= 100
-        if cap:
+        assert len(tags) >= 20
+        if cap and many:
             assert fr._slices.evicted > 100 and dm.device_calls > 10, (fr._slices.evicted, dm.device_calls)
-        else:
+        elif not cap:
             assert fr._slices.evicted == 0 and dm.device_calls == 0
 
 

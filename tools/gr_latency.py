@@ -6,18 +6,27 @@ import os
 import sys
 import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gc
 import numpy as np
 import torch  # noqa: F401
 from gr_adsb_amd import blocks, modulator as M
 
-fs = float(sys.argv[1]) if len(sys.argv) > 1 else 2e6
+# Python's cyclic collector scans every live container object on a full collection -- with torch imported that is ~10^6
+# objects, tens of milliseconds, triggered by the tags / PDUs of a multi-megasample call (measured: 3.7 us per PDU inside
+# message_port_pub, 0.3 without).  gc.freeze() after the imports (what a long-running flowgraph script does too) moves them
+# out of the collector's sight; "--no-freeze" measures without it.
+if "--no-freeze" not in sys.argv:
+    gc.freeze()
+
+fs = float(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else 2e6
 sps = int(fs // 1e6)
 L = 1 << 25
 x = M.mag2(M.synth_iq(1 << 22, fs, 1000, 3))
 x = np.tile(x, L // len(x))
 H = 8 * sps
 buf = np.concatenate([np.zeros(H - 1, np.float32), x])
-print("# fs %g Msps, 1000 bursts/s, host buffers (pageable numpy arrays, as GNU Radio hands them over)" % (fs / 1e6))
+print("# fs %g Msps, 1000 bursts/s, host buffers (pageable numpy arrays, as GNU Radio hands them over); gc.freeze() after imports: %s"
+      % (fs / 1e6, "--no-freeze" not in sys.argv))
 for paired in (False, True):
     for N in (2048, 8192, 32768, 262144, 1 << 20, 1 << 22, 1 << 24):
         fr = blocks.framer(fs, 0.01)
@@ -50,3 +59,30 @@ for paired in (False, True):
         print("%s chunk %8d samples: %8.3f ms per framer+demod call pair (framer %.3f, demod %.3f; %d pairs, %d PDUs) -> %8.1f Msamples/s"
               % ("paired     " if paired else "independent", N, (tf + td) / calls * 1e3, tf / calls * 1e3, td / calls * 1e3, calls, pdus,
                  samples / (tf + td) / 1e6), flush=True)
+
+if "--profile" in sys.argv:
+    # where a large paired call's time goes (cProfile, 4 M-sample chunks)
+    import cProfile
+    import pstats
+    N = 1 << 22
+    fr = blocks.framer(fs, 0.01)
+    dm = blocks.demod(fs, framer=fr)
+    out = np.empty(N, np.float32)
+    pr = cProfile.Profile()
+    pos = 0
+    for k in range(8):
+        fr._nread = fr._nwritten = pos
+        if k >= 2:
+            pr.enable()
+        fr.work([buf[pos:pos + N + H - 1]], [out])
+        pr.disable()
+        dm.tags_in = [t for t in fr.tags_out if t.offset >= pos]
+        dm._nread = dm._nwritten = pos
+        if k >= 2:
+            pr.enable()
+        dm.work([x[pos:pos + N]], [out])
+        pr.disable()
+        pos += N
+        fr.tags_out.clear()
+        dm.messages.clear()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(14)

@@ -4,10 +4,11 @@
 //              mask algebra -> pulse centre -> 16-chip preamble test -> for every match, while its samples are
 //              still in the wavefront's LDS window, the complete burst record (peak, median-of-100 noise,
 //              112-bit PPM slice, Mode S parity pre-filter): the stream is never read a second time
-//   k_longrun  (rare) pulses longer than the LDS window
-//   k_scan / k_gather / k_resolve / k_count / k_compact / k_publish
-//              order the centres and their records, apply the re-trigger gate as parallel chain walks, compact
-//              the survivors' records, hand the summary to the host
+//   k_order    finishes the (rare) pulses longer than the LDS window, turns the per-unit counts into offsets and puts the
+//              centre words into stream order -- one launch
+//   k_resolve / k_count / k_compact
+//              apply the re-trigger gate as parallel chain walks, compact the survivors' records; the last workgroup of
+//              k_compact hands the summary to the host
 //   k_slice    PPM slice (+ confidence ratio) for a tag list: the stand-alone demod block, and the opt-in
 //              confidence output of the fused path
 //
@@ -25,7 +26,9 @@
 // (marks a wavefront-uniform value so it lives in a scalar register), `adsb_readlane(int, lane)` and
 // `adsb_bitrep32(u32) -> u64` (every bit doubled: s_bitreplicate_b64_b32), `adsb_opaque(int)` (returns its argument
 // through an empty asm statement, so that nothing derived from it is treated as loop invariant) and
-// `adsb_ld_stream<Q>(const char*)` (one Q-sized load of streamed, single-use data), and the macro ADSB_LDS (the
+// `adsb_ld_stream<Q>(const char*)` (one Q-sized load of streamed, single-use data), `adsb_cold(const DetectArgs&)` (a pointer
+// to the same argument block as it lies in the kernel's argument memory, opaque to the optimiser: rarely needed fields are
+// loaded where they are used instead of occupying scalar registers across the tile loop), and the macro ADSB_LDS (the
 // address-space qualifier of workgroup-local memory, empty for the emulator): the
 // product translation unit adsb_hip.hip maps them to __builtin_amdgcn_wave_barrier() / _readfirstlane() /
 // _readlane(); tests/sim/sim_driver.cpp includes the test-only SIMT emulator instead, so the very same
@@ -219,8 +222,8 @@ __device__ __forceinline__ float xg_nb(const void* data, long long n, long long 
   return ok ? v : 0.0f;
 }
 
-template <int MODE>
-__device__ __forceinline__ bool above_at(const DetectArgs& a, long long i) {
+template <int MODE, class A>
+__device__ __forceinline__ bool above_at(const A& a, long long i) {
   if (i >= 0) return xg<MODE>(a.data, a.n, i, a.scale) >= a.thr;
   if (i == a.in0_base - 1) return a.prev_in0 >= a.thr;
   return 0.0f >= a.thr;
@@ -561,8 +564,11 @@ __device__ void burst_finish(const DetectArgs& a, const BurstFetch<MODE>& f, Rec
 // samples are read from global memory instead: pend_flush / the smp path below.)
 // Inlined into k_detect's hit loop: a real call would cost the callee's entry wait for ALL outstanding memory
 // operations, i.e. for the prefetch of the next tile, once per hit.
+// (the rarely needed fields -- data, n, in0_base, dem_hi -- are read through `c`, the kernel's argument block in memory,
+// where they are needed: see adsb_cold below)
+template <class CP>
 struct WinArgs {
-  const void* data; long long n, in0_base, dem_hi, origin; float scale; int sps;
+  CP c; long long origin; float scale; int sps;
 };
 constexpr int kMaxPend = 8;
 struct PendEntry { int slot; int p; unsigned flags; int pad_; unsigned long long ma, mb; };    // p = centre relative to the CURRENT t0
@@ -584,8 +590,8 @@ __device__ __forceinline__ void slice_window(const float* s_x, int p, int sps, i
 
 // EASY (wave-uniform, known per tile): the whole 100-sample noise window of every centre of the tile lies inside the
 // framer's input and every burst that starts in the tile ends inside the demod's -- the usual tile; nothing is clipped.
-template <int MODE, bool EASY>
-__device__ __forceinline__ void burst_from_window(WinArgs a, const float* s_x, long long t0, int p, unsigned xflags,
+template <int MODE, bool EASY, class CP>
+__device__ __forceinline__ void burst_from_window(WinArgs<CP> a, const float* s_x, long long t0, int p, unsigned xflags,
                                                   Rec* out, int slot, int lane, PendList* pend, int* n_pend,
                                                   unsigned& med_hint) {
   const int sps = a.sps, half = sps >> 1;
@@ -594,10 +600,11 @@ __device__ __forceinline__ void burst_from_window(WinArgs a, const float* s_x, l
   bool dem = true;
   if constexpr (!EASY) {
     long long wlo = P - kNoise;                              // framer.py:156: in0[max(0, pulse_idx-100) : pulse_idx]
-    if (wlo < a.in0_base) wlo = a.in0_base;
+    const long long in0_base = a.c->in0_base;
+    if (wlo < in0_base) wlo = in0_base;
     nwin = (int)(P - wlo);
     wl = (int)(wlo - t0);                                    // >= p - 100 >= -kBack
-    dem = P + 119ll * sps + half < a.dem_hi;                 // demod.py:76,82 (sps even)
+    dem = P + 119ll * sps + half < a.c->dem_hi;              // demod.py:76,82 (sps even)
   }
   const bool val0 = EASY || lane < nwin, val1 = lane + 64 < nwin;
   const float v0 = val0 ? s_x[wl + lane] : 0.0f;
@@ -622,7 +629,7 @@ __device__ __forceinline__ void burst_from_window(WinArgs a, const float* s_x, l
       return;
     } else {
       const int j0 = p + 8 * sps + lane * sps;               // demod.py:75,87
-      auto smp = [&](int j) -> float { return (j < kWWin) ? s_x[j] : xg<MODE>(a.data, a.n, t0 + j, a.scale); };
+      auto smp = [&](int j) -> float { return (j < kWWin) ? s_x[j] : xg<MODE>(a.c->data, a.c->n, t0 + j, a.scale); };
       const float x1 = smp(j0), x0 = smp(j0 + half);
       float y1 = 0.0f, y0 = 0.0f;
       if (lane < 48) { y1 = smp(j0 + 64 * sps); y0 = smp(j0 + 64 * sps + half); }
@@ -657,14 +664,14 @@ __device__ __forceinline__ void pend_step(PendList* pend, int* n_pend, const flo
 }
 
 // End of the wavefront's chunk: what is still pending takes its missing samples from global memory.
-template <int MODE>
-__device__ __forceinline__ void pend_flush(const PendList* pend, int n_pend, WinArgs a, const float* s_x, long long t0,
+template <int MODE, class CP>
+__device__ __forceinline__ void pend_flush(const PendList* pend, int n_pend, WinArgs<CP> a, const float* s_x, long long t0,
                                            Rec* my_recs, int lane) {
   const int sps = a.sps, half = sps >> 1;
   for (int i = 0; i < n_pend; ++i) {
     const PendEntry e = pend->e[i];                          // p relative to t0 (the last tile's start)
     const int ja = e.p + 8 * sps + lane * sps, jb = ja + 64 * sps;
-    auto smp = [&](int j) -> float { return (j < kWWin) ? s_x[j] : xg<MODE>(a.data, a.n, t0 + j, a.scale); };
+    auto smp = [&](int j) -> float { return (j < kWWin) ? s_x[j] : xg<MODE>(a.c->data, a.c->n, t0 + j, a.scale); };
     const bool ta = ja + half >= kWWin, tb = lane < 48 && jb + half >= kWWin;     // pairs no window has held
     float x1 = 0.0f, x0 = 0.0f, y1 = 0.0f, y0 = 0.0f;
     if (ta) { x1 = smp(ja); x0 = smp(ja + half); }
@@ -839,16 +846,21 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
   u16_alias* s_rise = reinterpret_cast<u16_alias*>(s_risea[wave]);
   PendList* pend = &s_penda[wave];
   int n_pend = 0;                                            // wave-uniform: bursts whose last bit samples have not arrived yet
+  // SGPR budget: the argument block is ~45 scalar registers, most of them needed once per chunk or in rare branches only.
+  // Those are read through cold() -- the same block as it lies in (kernarg) memory, one scalar load where it is used --
+  // instead of living in registers across the tile loop (every k_detect instance spilled 60-90 SGPRs into vector lanes,
+  // 8-15 v_readlane reloads per tile).  Hot fields (thr, scale, sps, origin, rec_cap, long_aware) stay by-value.
+  auto cold = [&]() { return adsb_cold(a); };
   const long long unit = (long long)block * kWaves + wave;
-  const long long c0 = unit * a.chunk;
-  long long c1 = c0 + a.chunk;
-  if (c1 > a.scan_hi) c1 = a.scan_hi;
+  const long long c0 = unit * cold()->chunk;
+  long long c1 = c0 + cold()->chunk;
+  if (c1 > cold()->scan_hi) c1 = cold()->scan_hi;
   const int half = HALF ? HALF : (a.sps >> 1);
   int nrec = 0;                                              // wave-uniform running count of this unit's list
   unsigned uflags = 0u;
   int lp = -1;                                               // per lane: largest paired pulse centre so far, relative to c0
   unsigned med_hint = 0u;                                    // wave-uniform: median key of this wavefront's previous burst
-  int pred = adsb_uniform(above_at<MODE>(a, c0 - 1) ? 1 : 0);
+  int pred = adsb_uniform(above_at<MODE>(*cold(), c0 - 1) ? 1 : 0);
   unsigned long long* my_cands = a.cands + unit * a.rec_cap;
   Rec* my_recs = a.recs + unit * a.rec_cap;
   const float thr = a.thr;
@@ -856,12 +868,12 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
   const int thr_bits = __builtin_bit_cast(int, thr);
 
   // virtual rise in the zero history in front of a fresh stream: only possible when 0 >= thr
-  if (unit == 0 && a.scan_lo < 0 && (0.0f >= a.thr) && !(a.prev_in0 >= a.thr)) {
+  if (unit == 0 && cold()->scan_lo < 0 && (0.0f >= a.thr) && !(cold()->prev_in0 >= a.thr)) {
     uflags |= 1u;
     if (lane == 0 && 0 < a.rec_cap) {
-      my_cands[0] = cand_make(a.scan_lo, kPending | kNoMatch);
-      const int li = atomicAdd(a.long_count, 1);
-      if (li < a.long_cap) { LongRise e; e.rise = a.scan_lo; e.blk = 0; e.slot = 0; a.longlist[li] = e; }
+      my_cands[0] = cand_make(cold()->scan_lo, kPending | kNoMatch);
+      const int li = atomicAdd(cold()->long_count, 1);
+      if (li < cold()->long_cap) { LongRise e; e.rise = cold()->scan_lo; e.blk = 0; e.slot = 0; cold()->longlist[li] = e; }
     }
     nrec = 1;
   }
@@ -882,21 +894,22 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
     ntile = (int)nt;
     // c0 + it*T + T < c1  and  c0 + it*T + 2T + kFwd <= n
     long long re = tiles_below(c1 - c0 - kWTile);
-    const long long re2 = tiles_below(a.n - c0 - 2 * kWTile - kFwd + 1);
+    const auto C = cold();
+    const long long re2 = tiles_below(C->n - c0 - 2 * kWTile - kFwd + 1);
     if (re2 < re) re = re2;
     it_re = clampi(re, nt);
-    it_rag = clampi(tiles_below(a.n - c0 - kFwd - kWTile + 1), nt);      // c0 + it*T + kFwd + T <= n: body inside the buffer
+    it_rag = clampi(tiles_below(C->n - c0 - kFwd - kWTile + 1), nt);      // c0 + it*T + kFwd + T <= n: body inside the buffer
     // scan_lo <= c0 + it*T,  c0 + it*T + T <= scan_hi,  c0 + it*T + kWWin < fall_hi
-    const long long i0 = tiles_below(a.scan_lo - c0);
-    long long i1 = tiles_below(a.scan_hi - c0 - kWTile + 1);
-    const long long i1f = tiles_below(a.fall_hi - c0 - kWWin);
+    const long long i0 = tiles_below(C->scan_lo - c0);
+    long long i1 = tiles_below(C->scan_hi - c0 - kWTile + 1);
+    const long long i1f = tiles_below(C->fall_hi - c0 - kWWin);
     if (i1f < i1) i1 = i1f;
     it_i0 = clampi(i0, nt);
     it_i1 = clampi(i1, nt);
     // "easy" tiles (burst_from_window<.., EASY>): interior, c0 + it*T - kNoise >= in0_base, and the latest centre a tile
     // can hold (kMaxCentre) still has its last bit sample in front of dem_hi
-    long long e0 = tiles_below(a.in0_base + kNoise - c0);
-    long long e1 = tiles_below(a.dem_hi - c0 - kMaxCentre - 119ll * a.sps - (a.sps >> 1));
+    long long e0 = tiles_below(C->in0_base + kNoise - c0);
+    long long e1 = tiles_below(C->dem_hi - c0 - kMaxCentre - 119ll * a.sps - (a.sps >> 1));
     if (e0 < i0) e0 = i0;
     if (e1 > i1) e1 = i1;
     it_e0 = clampi(e0, nt);
@@ -911,10 +924,11 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
   // chunk instead of seven in a row.
   auto head_fill = [&](const int lane) {
     constexpr int NQ = (kBack + kFwd) / 64;
-    if (a.n > 0) {                                             // wave-uniform
+    const auto C = cold();
+    if (C->n > 0) {                                            // wave-uniform
       float hv[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) hv[q] = xg_nb<MODE>(a.data, a.n, c0 - kBack + lane + 64 * q, a.scale);
+      for (int q = 0; q < NQ; ++q) hv[q] = xg_nb<MODE>(C->data, C->n, c0 - kBack + lane + 64 * q, a.scale);
 #pragma unroll
       for (int q = 0; q < NQ; ++q) s_x[lane + 64 * q - kBack] = hv[q];
     } else {
@@ -950,9 +964,9 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
           if (wd < kMaskDwords && cur) f = wd * 32 + __builtin_ctz(cur);
         }
         if (f < 0) {
-          if (EASY || interior || t0 + kWWin < a.fall_hi) res = kHitValid | kHitLongPulse | (unsigned)r;    // k_longrun
-          else if (!a.end_is_call_end) hflag = true;
-        } else if (EASY || interior || t0 + f < a.fall_hi) {
+          if (EASY || interior || t0 + kWWin < cold()->fall_hi) res = kHitValid | kHitLongPulse | (unsigned)r;    // long pulse: k_order
+          else if (!cold()->end_is_call_end) hflag = true;
+        } else if (EASY || interior || t0 + f < cold()->fall_hi) {
           const int p = (r + f) >> 1;                    // framer.py:113
           lp = imax(lp, trel + p);                        // (centres increase along the stream)
           bool match = true;
@@ -965,7 +979,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
 #pragma unroll 1
             for (int k = 0; k < 16; ++k) {
               const int idx = p + k * half;
-              const float v = (idx < kWWin) ? s_x[idx] : xg<MODE>(a.data, a.n, t0 + idx, a.scale);
+              const float v = (idx < kWWin) ? s_x[idx] : xg<MODE>(cold()->data, cold()->n, t0 + idx, a.scale);
               chips |= (v > hp ? 1u : 0u) << k;
             }
             match = chips == kTemplate;
@@ -974,12 +988,12 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
             res = kHitValid | (unsigned)p;
             if (a.long_aware) {                          // first data bit (demod.py:87-95, k = 0): DF >= 16 = long reply
               const int i1 = p + 16 * half, i0 = i1 + half;
-              const float v1 = (i1 < kWWin) ? s_x[i1] : xg<MODE>(a.data, a.n, t0 + i1, a.scale);
-              const float v0 = (i0 < kWWin) ? s_x[i0] : xg<MODE>(a.data, a.n, t0 + i0, a.scale);
+              const float v1 = (i1 < kWWin) ? s_x[i1] : xg<MODE>(cold()->data, cold()->n, t0 + i1, a.scale);
+              const float v0 = (i0 < kWWin) ? s_x[i0] : xg<MODE>(cold()->data, cold()->n, t0 + i0, a.scale);
               if (v1 > v0) res |= kHitLongHint;
             }
           }
-        } else if (!a.end_is_call_end) {
+        } else if (!cold()->end_is_call_end) {
           hflag = true;
         }
       }
@@ -1006,13 +1020,13 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
         if (lane == 0) {
           const long long rg = t0 + v;
           my_cands[slot2] = cand_make(rg, kPending | kNoMatch);
-          const int li = atomicAdd(a.long_count, 1);
-          if (li < a.long_cap) { LongRise le; le.rise = rg; le.blk = (int)unit; le.slot = slot2; a.longlist[li] = le; }
+          const int li = atomicAdd(cold()->long_count, 1);
+          if (li < cold()->long_cap) { LongRise le; le.rise = rg; le.blk = (int)unit; le.slot = slot2; cold()->longlist[li] = le; }
         }
       } else {
         const bool lh = (e & kHitLongHint) != 0;
         if (lane == 0) my_cands[slot2] = cand_make(t0 + (long long)v, lh ? kLongHint : 0u);
-        burst_from_window<MODE, EASY>(WinArgs{a.data, a.n, a.in0_base, a.dem_hi, a.origin, a.scale, a.sps}, s_x, t0, v,
+        burst_from_window<MODE, EASY>(WinArgs<decltype(cold())>{cold(), a.origin, a.scale, a.sps}, s_x, t0, v,
                                       lh ? kRecLongHint : 0u, my_recs + slot2, slot2, lane, pend, &n_pend, med_hint);
       }
     }
@@ -1043,7 +1057,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
       unsigned own16 = 0xFFFFu;
       if (!interior) {
         const long long sbase = t0 + 16ll * lane;
-        own16 = (unsigned)bit_range(a.scan_lo - sbase, a.scan_hi - sbase) & 0xFFFFu;
+        own16 = (unsigned)bit_range(cold()->scan_lo - sbase, cold()->scan_hi - sbase) & 0xFFFFu;
       }
       unsigned piece = m16 & ~prev16 & own16;                 // rises among my 16 samples
       const unsigned long long anyr = __ballot(piece != 0u), anyf = __ballot((~m16 & prev16 & own16) != 0u);
@@ -1073,7 +1087,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
 
     if (n_pend > 0 && it + 1 == ntile) {                     // end of this wavefront's chunk
       adsb_wave_sync();
-      pend_flush<MODE>(pend, n_pend, WinArgs{a.data, a.n, a.in0_base, a.dem_hi, a.origin, a.scale, a.sps}, s_x, t0, my_recs, lane);
+      pend_flush<MODE>(pend, n_pend, WinArgs<decltype(cold())>{cold(), a.origin, a.scale, a.sps}, s_x, t0, my_recs, lane);
       n_pend = 0;
     }
     // what the next tile inherits: back + forward halo (floats), the mask units of the forward halo and the last
@@ -1093,7 +1107,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
   };
 
   const int lane_outer = lane;
-  if (a.n >= kWTile) {
+  if (cold()->n >= kWTile) {
     // -- the streaming loop.  The body of tile `it` sits in registers, fetched one tile ahead; every register is reloaded
     // the moment its samples are converted -- from the next tile's body or, when there is none inside the buffer (last
     // tile of the chunk, ragged end of the buffer: one tile in ~200), from `clamp`, the last whole tile of the buffer: a
@@ -1101,8 +1115,8 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
     // prefetch registers were copied at the join, 32 moves per tile that had to wait for the loads just issued.)
     // A tile whose own body is not entirely inside the buffer (it >= it_rag: at most two per launch) was "prefetched"
     // from `clamp` too; its floats are then written by the scalar loop, zeros past the end.
-    const char* const clamp = reinterpret_cast<const char*>(a.data) + (((a.n - kWTile) * (long long)BPS) & ~15ll);
-    const char* nb = reinterpret_cast<const char*>(a.data) + (c0 + kFwd) * (long long)BPS;      // this tile's body
+    const char* const clamp = reinterpret_cast<const char*>(cold()->data) + (((cold()->n - kWTile) * (long long)BPS) & ~15ll);
+    const char* nb = reinterpret_cast<const char*>(cold()->data) + (c0 + kFwd) * (long long)BPS;      // this tile's body
     Body<MODE> body;
     if (ntile > 0) {
       body_issue(body, it_rag > 0 ? nb : clamp, lane);
@@ -1117,7 +1131,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
       const int mx = body_commit<MODE, true>(body, s_x + kFwd, a.scale, lane, it < it_re ? nb : clamp);
       bool active = !thr_pos || __ballot(mx >= thr_bits) != 0ull;
       if (it >= it_rag) {
-        for (int i = lane; i < kWTile; i += 64) s_x[kFwd + i] = xg<MODE>(a.data, a.n, t0 + kFwd + i, a.scale);
+        for (int i = lane; i < kWTile; i += 64) s_x[kFwd + i] = xg<MODE>(cold()->data, cold()->n, t0 + kFwd + i, a.scale);
         active = true;
       }
       process_tile(it, t0, active, lane);
@@ -1128,7 +1142,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
     for (int it = 0; it < ntile; ++it) {
       const int lane = adsb_opaque(lane_outer);
       const long long t0 = c0 + (long long)it * kWTile;
-      for (int i = lane; i < kWTile; i += 64) s_x[kFwd + i] = xg<MODE>(a.data, a.n, t0 + kFwd + i, a.scale);
+      for (int i = lane; i < kWTile; i += 64) s_x[kFwd + i] = xg<MODE>(cold()->data, cold()->n, t0 + kFwd + i, a.scale);
       process_tile(it, t0, true, lane);
     }
   }
@@ -1136,9 +1150,9 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
 #pragma unroll
   for (int d2 = 32; d2 >= 1; d2 >>= 1) lp = imax(lp, __shfl_xor(lp, d2));
   if (lane == 0) {
-    a.blk_count[unit] = nrec;
-    a.blk_lastp[unit] = lp >= 0 ? c0 + lp : kNoIndex;
-    a.blk_flags[unit] = uflags;
+    cold()->blk_count[unit] = nrec;
+    cold()->blk_lastp[unit] = lp >= 0 ? c0 + lp : kNoIndex;
+    cold()->blk_flags[unit] = uflags;
   }
 }
 template <int MODE, int HALF>
@@ -1151,12 +1165,10 @@ __global__ void __launch_bounds__(kThreads, kMinWaves) k_detect(DetectArgs a) {
 // with global-memory taps and overwrites the placeholder.  Rare (CW / overload, or dense overlapping
 // bursts): it is launched after every k_detect and returns at once when the list is empty.
 template <int MODE>
-__device__ __forceinline__ void longrun_body(int bid, int nb, const DetectArgs& a) {
+__device__ __forceinline__ void longrun_entry(const DetectArgs& a, int e) {
   __shared__ unsigned long long s_found;   // fall index relative to rise+1
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int n_entries = *a.long_count;                 // written by k_detect, usually 0: then this is a no-op
-  if (n_entries > a.long_cap) n_entries = a.long_cap;
-  for (int e = bid; e < n_entries; e += nb) {
+  {
     const LongRise le = a.longlist[e];
     const long long limit = a.fall_hi;
     const long long start = le.rise + 1;
@@ -1205,9 +1217,13 @@ __device__ __forceinline__ void longrun_body(int bid, int nb, const DetectArgs& 
   }
 }
 template <int MODE>
-__global__ void __launch_bounds__(kThreads) k_longrun(DetectArgs a) {
-  longrun_body<MODE>((int)blockIdx.x, (int)gridDim.x, a);
+__device__ __forceinline__ void longrun_body(int bid, int nb, const DetectArgs& a) {
+  int n_entries = *a.long_count;                 // written by k_detect, usually 0: then this is a no-op
+  if (n_entries > a.long_cap) n_entries = a.long_cap;
+  for (int e = bid; e < n_entries; e += nb) longrun_entry<MODE>(a, e);
 }
+// (bulk passes: k_order's workgroups take the entries whose list they own; small passes: longrun_body in k_tail_small /
+// k_pass_small)
 
 // Exclusive prefix sum of one int per thread over a 256-thread workgroup (wave shuffles + 4 LDS words).
 // Every thread must call it; *total receives the sum on every thread.
@@ -1311,18 +1327,6 @@ __device__ __forceinline__ void scan_body(const int* blk_count, const long long*
     sum->long_count = *long_count; sum->n_kept = 0; sum->last_kept_p = kNoIndex;
   }
 }
-__global__ void __launch_bounds__(kThreads) k_scan(const int* blk_count, const long long* blk_lastp,
-                                                   const unsigned* blk_flags, int nblk, int rec_cap,
-                                                   const int* long_count, const unsigned long long* long_lastp,
-                                                   int* blk_off, Summary* sum, int dyn_ints) {
-  ADSB_DYN_LDS_INT(s_scan_dyn);                                 // the launch's dynamic LDS (0 or 8 KB)
-  __shared__ int s_scan_cnt[kScanRound];
-  if (dyn_ints >= kScanRoundBig)                                // wave-uniform
-    scan_body<kScanRoundBig>(blk_count, blk_lastp, blk_flags, nblk, rec_cap, long_count, long_lastp, blk_off, sum, s_scan_dyn);
-  else
-    scan_body<kScanRound>(blk_count, blk_lastp, blk_flags, nblk, rec_cap, long_count, long_lastp, blk_off, sum, s_scan_cnt);
-}
-
 // ---- k_gather: per-unit lists of centre words -> one list in stream order; the burst records stay where k_detect wrote
 // them (their list slot travels with the word): round 2 copied them too, 32 MB more of scattered traffic per 2^30-sample
 // pass beside a k_detect that is bound by HBM ------------------------------------------------------------------------
@@ -1345,9 +1349,89 @@ __device__ __forceinline__ void gather_body(int bid, int nb, const unsigned long
     }
   }
 }
-__global__ void __launch_bounds__(kThreads) k_gather(const unsigned long long* cands, const int* blk_count, const int* blk_off,
-                                                     int nblk, int rec_cap, unsigned long long* sorted, unsigned* sorted_src) {
-  gather_body((int)blockIdx.x, (int)gridDim.x, cands, blk_count, blk_off, nblk, rec_cap, sorted, sorted_src);
+
+// ---- k_order: the first tail kernel of a BULK pass -- long pulses, per-unit counts -> offsets, centre words into stream
+// order -- what k_longrun + k_scan + k_gather did in three launches (one of them a single workgroup, 42 us for the 40 k lists
+// of a 2^30-sample pass).  Workgroup g owns kOrderLists consecutive lists, one per thread:
+//   0. the long pulses k_detect listed for one of ITS lists (usually none): their placeholder word / record is finished by
+//      this workgroup before it reads the list (longrun_entry);
+//   1. count, last paired centre, flags of its lists; maximum / OR go to the pass's accumulator with ONE atomic per workgroup;
+//   2. the number of centres in front of its first list: every workgroup sums those counts itself (<= 160 KB of L2-resident
+//      ints, 16-byte loads, all in flight together) -- no second launch, no look-back chain;
+//   3. each thread copies the words of its list (a dozen) to their final places, four loads in flight at a time.
+// The summary's fields are completed by k_compact (OrderAcc -> Summary), which also hands the summary to the host.
+constexpr int kOrderLists = kThreads;
+struct OrderAcc { unsigned long long lastp_biased; unsigned flags; unsigned pad_; };
+template <int MODE>
+__global__ void __launch_bounds__(kThreads) k_order(DetectArgs a, int nblk, unsigned long long* sorted, unsigned* sorted_src,
+                                                   Summary* sum, OrderAcc* acc) {
+  __shared__ long long s_lp[kWaves];
+  __shared__ unsigned s_fl[kWaves];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, bid = (int)blockIdx.x;
+  const int rec_cap = a.rec_cap;
+  // 0. long pulses of this workgroup's lists (workgroup-uniform loop: every thread sees the same list)
+  int n_long = *a.long_count;
+  if (n_long > a.long_cap) n_long = a.long_cap;
+  for (int e = 0; e < n_long; ++e)
+    if (a.longlist[e].blk / kOrderLists == bid) longrun_entry<MODE>(a, e);
+  __syncthreads();
+  // 1. my list
+  const int b = bid * kOrderLists + tid;
+  const bool in = b < nblk;
+  const int bc = in ? b : nblk - 1;
+  int cnt = a.blk_count[bc];
+  long long lp = a.blk_lastp[bc];
+  unsigned fl = a.blk_flags[bc];
+  if (!in) { cnt = 0; lp = kNoIndex; fl = 0u; }
+  if (cnt > rec_cap) { fl |= 0x80000000u; cnt = rec_cap; }       // bit 31: some unit overflowed its list
+  // 2. centres in front of this workgroup's first list
+  int before = 0;
+  {
+    struct alignas(16) I4 { int x, y, z, w; };
+    const int nfront = bid * kOrderLists;                       // a multiple of 4: whole 16-byte groups only
+    const I4* c4 = reinterpret_cast<const I4*>(a.blk_count);
+    for (int i = tid; i < nfront / 4; i += kThreads) {
+      const I4 v = c4[i];
+      before += (v.x < rec_cap ? v.x : rec_cap) + (v.y < rec_cap ? v.y : rec_cap) + (v.z < rec_cap ? v.z : rec_cap) +
+                (v.w < rec_cap ? v.w : rec_cap);
+    }
+  }
+  int front = 0, total = 0;
+  (void)block_excl_scan(before, &front);                        // (barriers inside) front = sum over the workgroup
+  const int run = front + block_excl_scan(cnt, &total);
+  // 3. words to their final places
+  {
+    const long long src = (long long)b * rec_cap;
+    for (int j = 0; j < cnt; j += 4) {
+      unsigned long long w[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = a.cands[src + (j + q < cnt ? j + q : j)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (j + q < cnt) {
+          sorted[run + j + q] = w[q];
+          sorted_src[run + j + q] = (unsigned)(src + j + q);   // where its 32-byte record lies: read once, by k_compact
+        }
+    }
+  }
+  // workgroup reductions: max of lastp, OR of flags (wave shuffles, then 4 words), one atomic each
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const long long ol = __shfl_xor(lp, d);
+    const unsigned of = __shfl_xor(fl, d);
+    if (ol > lp) lp = ol;
+    fl |= of;
+  }
+  if (lane == 0) { s_lp[wave] = lp; s_fl[wave] = fl; }
+  __syncthreads();
+  if (tid == 0) {
+    long long L = kNoIndex;
+    unsigned F = 0u;
+    for (int w = 0; w < kWaves; ++w) { if (s_lp[w] > L) L = s_lp[w]; F |= s_fl[w]; }
+    if (L != kNoIndex) atomicMax(&acc->lastp_biased, (unsigned long long)(L + (1ll << 62)));
+    if (F) atomicOr(&acc->flags, F);
+    if (bid == (int)gridDim.x - 1) sum->n_rec = front + total;
+  }
 }
 
 // ---- k_resolve: the re-trigger gate (framer.py:121-123,165) as parallel chain walks -----------------
@@ -1433,16 +1517,57 @@ __global__ void __launch_bounds__(kThreads) k_count(const unsigned long long* so
 // Emits the survivors' burst records (built by k_detect / k_longrun, ordered by k_gather) with kKept / kHead added.
 __device__ __forceinline__ void compact_body(int bid, int nb, const unsigned long long* sorted, const Rec* recs, const unsigned* sorted_src,
                                              Summary* sum, const int* seg_count, unsigned fmask, unsigned fwant, int head_n,
-                                             Rec* out, int out_cap, int* long_count, unsigned long long* long_lastp) {
+                                             Rec* out, int out_cap, int* long_count, unsigned long long* long_lastp,
+                                             OrderAcc* acc = nullptr, Summary* host_sum = nullptr) {
   __shared__ int s_c[kWaves];
   __shared__ int s_pre[kWaves], s_tot[kWaves];
   const int n = sum->n_rec;
   const int nseg = (n + kThreads - 1) / kThreads;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (bid == 0 && host_sum) {
+    // Bulk pass: workgroup 0 completes the pass's 48-byte summary ALONE and stores it straight into the caller-visible
+    // (pinned, mapped) host copy -- no publishing kernel, no cross-workgroup hand-over (a "last workgroup done" counter needs a
+    // device-scope fence per workgroup: an L2 write-back on a part with one L2 per XCD, measured 21 -> 41 us for this kernel).
+    // k_order left the maximum / OR of the lists in the accumulator; the number of survivors is the sum of the segment
+    // counts every workgroup computes anyway; the last survivor is found by looking at the END of the ordered list.
+    int tot = 0;
+    for (int j = threadIdx.x; j < nseg; j += kThreads) tot += seg_count[j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+    if (lane == 0) s_tot[wave] = tot;
+    __syncthreads();
+    tot = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+    __syncthreads();
+    long long lastk = kNoIndex;
+    if (tot > 0) {
+      for (int hi = n; hi > 0 && lastk == kNoIndex; hi -= kThreads) {      // workgroup-uniform loop
+        const int i = hi - 1 - (int)threadIdx.x;
+        const unsigned long long c = i >= 0 ? sorted[i] : 0ull;
+        const bool k = i >= 0 && survives(c, i, fmask, fwant, head_n);
+        const unsigned long long m = __ballot(k);
+        if (lane == 0) s_c[wave] = m ? __builtin_ctzll(m) : 64;            // smallest lane = largest index
+        __syncthreads();
+        int w = 0;
+        while (w < kWaves && s_c[w] == 64) ++w;
+        if (w < kWaves) lastk = cand_p(sorted[hi - 1 - (w * 64 + s_c[w])]);
+        __syncthreads();
+      }
+    }
+    if (threadIdx.x == 0) {
+      const unsigned F = acc->flags;
+      const unsigned long long lb = acc->lastp_biased > *long_lastp ? acc->lastp_biased : *long_lastp;
+      Summary f;
+      f.n_rec = n; f.n_kept = tot; f.overflow = (int)((F >> 31) & 1u); f.long_count = *long_count; f.flags = F & 0x7FFFFFFFu;
+      f.pad_ = 0; f.lastp = lb ? (long long)lb - (1ll << 62) : kNoIndex; f.last_kept_p = lastk;
+      *host_sum = f;
+      *sum = f;
+      acc->flags = 0u; acc->lastp_biased = 0ull;             // empty again for the slot's next pass
+    }
+  }
   if (bid == 0 && threadIdx.x == 0) {
-    *long_count = 0;        // k_scan has consumed the long-pulse list: leave it empty for the slot's next pass
+    *long_count = 0;        // the long-pulse list has been consumed: leave it empty for the slot's next pass
     *long_lastp = 0ull;
-    if (nseg == 0) sum->n_kept = 0;
+    if (nseg == 0 && !host_sum) sum->n_kept = 0;
   }
   for (int seg = bid; seg < nseg; seg += nb) {
     // exclusive prefix of this segment and the grand total
@@ -1465,14 +1590,14 @@ __device__ __forceinline__ void compact_body(int bid, int nb, const unsigned lon
     const int total = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
     for (int w = 0; w < wave; ++w) off += s_c[w];
     off += lanes_below(m, lane);
-    if (seg == 0 && threadIdx.x == 0) sum->n_kept = total;
+    if (seg == 0 && threadIdx.x == 0 && !host_sum) sum->n_kept = total;
     if (k && off < out_cap) {
       Rec r = recs[sorted_src[i]];
       unsigned fl = cand_flags(c) & (kKept | kHead);
       if ((unsigned)(r.w[3] >> 48) & kDemod) fl |= parity_flags_of(r.w[2], r.w[3]);
       r.w[3] |= (unsigned long long)fl << 48;
       out[off] = r;
-      if (off == total - 1) sum->last_kept_p = cand_p(c);
+      if (off == total - 1 && !host_sum) sum->last_kept_p = cand_p(c);
     }
     __syncthreads();
   }
@@ -1480,15 +1605,9 @@ __device__ __forceinline__ void compact_body(int bid, int nb, const unsigned lon
 __global__ void __launch_bounds__(kThreads) k_compact(const unsigned long long* sorted, const Rec* recs, const unsigned* sorted_src, Summary* sum,
                                                       const int* seg_count, unsigned fmask, unsigned fwant, int head_n,
                                                       Rec* out, int out_cap, int* long_count,
-                                                      unsigned long long* long_lastp) {
+                                                      unsigned long long* long_lastp, OrderAcc* acc, Summary* host_sum) {
   compact_body((int)blockIdx.x, (int)gridDim.x, sorted, recs, sorted_src, sum, seg_count, fmask, fwant, head_n, out, out_cap,
-               long_count, long_lastp);
-}
-
-// ---- k_publish: the pass's 48-byte summary, final once k_compact is done, stored straight into the caller-visible
-// (pinned, mapped) host copy -- no separate copy operation on the tail of the pass
-__global__ void k_publish(const Summary* sum, Summary* host_sum) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *host_sum = *sum;
+               long_count, long_lastp, acc, host_sum);
 }
 
 // ---- k_tail_small: the whole tail of a SMALL pass (a GNU Radio work() call: a few lists, a few hundred centres at most)

@@ -1,7 +1,7 @@
 // adsb_hip.hip -- host side of libadsb_hip.so (C ABI in include/adsb_hip.h) for gfx950.
 // Owns device memory, pinned staging and the launch sequence
-//   k_detect (the one pass over the samples: centres AND their burst records) -> k_longrun (no-op unless needed)
-//   -> k_scan -> k_gather -> k_resolve -> k_count -> k_compact -> k_publish          (sparse lists only)
+//   k_detect (the one pass over the samples: centres AND their burst records)
+//   -> k_order (long pulses, counts -> offsets, words in stream order) -> k_resolve -> k_count -> k_compact (+ summary to the host)
 // There is deliberately no CPU implementation of the path in this library.
 //
 // The library reads no environment variable.
@@ -130,6 +130,18 @@ __device__ __forceinline__ unsigned long long adsb_bitrep32(unsigned x) {
   return r;
 }
 
+// The kernel's own argument block in (kernarg) memory: DetectArgs is the FIRST parameter of every kernel that runs
+// detect_body, so the block starts with it.  Through an empty asm statement, so that loads through it are neither hoisted
+// out of the tile loop nor merged with the by-value copy: a field read through this pointer costs one s_load where it is
+// used and no scalar register anywhere else.
+namespace adsb { struct DetectArgs; }
+typedef const __attribute__((address_space(4))) adsb::DetectArgs* adsb_cold_ptr;
+__device__ __forceinline__ adsb_cold_ptr adsb_cold(const adsb::DetectArgs&) {
+  auto p = __builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return (adsb_cold_ptr)p;
+}
+
 #include "adsb_device.h"
 #include "adsb_plan.h"
 #include "../../include/adsb_hip.h"
@@ -145,14 +157,16 @@ struct DevBuf {
   size_t cap = 0;
 };
 
-// d_misc layout: [0] int long_count, [8] u64 long_lastp, [64] Summary
+// d_misc layout: [0] int long_count, [8] u64 long_lastp, [16] OrderAcc (k_order's accumulator), [64] Summary
 struct Misc {
   int long_count;
   int pad;
   unsigned long long long_lastp;
-  char fill[48];
+  OrderAcc acc;
+  char fill[32];
   Summary sum;
 };
+static_assert(sizeof(OrderAcc) == 16, "Misc layout");
 
 // Everything one in-flight call needs on the device and in pinned host memory.  Several slots let call i+1
 // run on the GPU while the records of call i travel over PCIe (adsb_submit_* / adsb_wait), and -- host-fed -- while
@@ -362,8 +376,9 @@ int detect_occupancy(unsigned dyn) {
   return nb;
 }
 template <int MODE>
-void launch_longrun(hipStream_t st, const DetectArgs& a) {
-  hipLaunchKernelGGL((k_longrun<MODE>), dim3(64), dim3(kThreads), 0, st, a);
+void launch_order(hipStream_t st, int grid, unsigned dyn, const DetectArgs& a, int nblk, unsigned long long* sorted, unsigned* sorted_src,
+                  Summary* sum, OrderAcc* acc) {
+  hipLaunchKernelGGL((k_order<MODE>), dim3(grid), dim3(kThreads), dyn, st, a, nblk, sorted, sorted_src, sum, acc);
 }
 template <int MODE>
 void launch_tail_small(hipStream_t st, const DetectArgs& a, const TailArgs& t) {
@@ -417,27 +432,18 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
     HIPCHK(c, hipStreamWaitEvent(c->tail_stream, dep, 0));
     ts = c->tail_stream;
   }
-  // no-op unless k_detect listed pulses longer than its LDS window
-  ADSB_BY_MODE(pl.mode, launch_longrun, ts, a);
   // Every tail kernel is small enough to run on a CU BESIDE five resident k_detect workgroups (tests/test_abi.py holds
   // the limits).  Whether it should is a choice: beside the next pass's k_detect the tail finishes ~0.25 ms after its own
-  // k_detect (results one pass earlier, two passes in flight suffice) but costs that k_detect 1-2 % (measured 1.58 vs
-  // 1.56 ms per 2^30-sample pass); kept out -- k_scan, the first kernel of the chain, is launched with 8 KB of unused
-  // dynamic LDS, more than five k_detect workgroups leave free on a CU -- it runs when that k_detect drains.
-  // Throughput is the default, ADSB_FLAG_LOW_LATENCY selects the other.
-  // (8 KB: measured.  A padding sized to what k_detect leaves free -- 16 KB for complex64, 25 KB beside the narrow formats'
-  // four workgroups -- keeps the chain out more strictly and was SLOWER on every workload: int16 791 vs 1039 Gsamples/s)
-  const unsigned scan_pad = (c->flags & ADSB_FLAG_LOW_LATENCY) ? 0u : 8192u;
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(kThreads), scan_pad, ts, (const int*)a.blk_count,
-                     (const long long*)a.blk_lastp, (const unsigned*)a.blk_flags, s.nlists, s.rec_cap,
-                     (const int*)a.long_count, (const unsigned long long*)a.long_lastp, (int*)s.d_blk_off.p, &misc->sum,
-                     (int)(scan_pad / sizeof(int)));               // the padding doubles as k_scan's staging buffer
-  const int gl = (s.nlists + kWaves - 1) / kWaves;                // k_gather: one wavefront per list
-  const int gg = gl < 1024 ? gl : 1024;
+  // k_detect (results one pass earlier, two passes in flight suffice) but costs that k_detect 1-2 %; kept out -- k_order,
+  // the first kernel of the chain, is launched with 8 KB of unused dynamic LDS, more than five k_detect workgroups leave
+  // free on a CU -- it runs when that k_detect drains.  Throughput is the default, ADSB_FLAG_LOW_LATENCY selects the other.
+  // (8 KB: measured.  A padding sized to what k_detect leaves free keeps the chain out more strictly and was SLOWER on
+  // every workload: int16 791 vs 1039 Gsamples/s)
+  const unsigned order_pad = (c->flags & ADSB_FLAG_LOW_LATENCY) ? 0u : 8192u;
   unsigned long long* sorted = (unsigned long long*)s.d_sorted.p;
   unsigned* sorted_src = (unsigned*)s.d_sorted_src.p;
-  hipLaunchKernelGGL(k_gather, dim3(gg), dim3(kThreads), 0, ts, (const unsigned long long*)a.cands,
-                     (const int*)a.blk_count, (const int*)s.d_blk_off.p, s.nlists, s.rec_cap, sorted, sorted_src);
+  ADSB_BY_MODE(pl.mode, launch_order, ts, (s.nlists + kOrderLists - 1) / kOrderLists, order_pad, a, s.nlists, sorted, sorted_src,
+               &misc->sum, &misc->acc);
   const int ag = 512;
   unsigned fmask = 0u, fwant = 0u;
   if (pl.gate) {
@@ -447,12 +453,11 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   }
   hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted,
                      (const Summary*)&misc->sum, fmask, fwant, pl.head_n, (int*)s.d_seg.p);
+  // k_compact's last workgroup stores the summary straight into s.h_sum (pinned host memory, device-visible): visible to the
+  // host once the `done` event below has completed
   hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted, (const Rec*)a.recs, (const unsigned*)sorted_src,
                      &misc->sum, (const int*)s.d_seg.p, fmask, fwant, pl.head_n, (Rec*)(s.direct ? s.h_out : s.d_out.p), (int)s.tot,
-                     a.long_count, a.long_lastp);
-  // the summary goes straight into s.h_sum (pinned host memory, device-visible): visible to the host once the `done`
-  // event below has completed
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ts, (const Summary*)&misc->sum, s.h_sum);
+                     a.long_count, a.long_lastp, &misc->acc, s.h_sum);
   HIPCHK(c, hipEventRecord(s.done, ts));
   return 0;
 }

@@ -122,13 +122,8 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     sum = sum_host;
     if (g_conf_out) SIM_BY_MODE(mode, k_confidence, 2, kThreads, a, (const Rec*)outv.data(), (const Summary*)&sum, (int)tot, g_conf_out);
   } else {
-    SIM_BY_MODE(mode, k_longrun, 3, kThreads, a);
-    hipsim::launch(k_scan, 1, kThreads, (const int*)blk_count.data(), (const long long*)blk_lastp.data(),
-                   (const unsigned*)blk_flags.data(), nlists, rec_cap, (const int*)&long_count,
-                   (const unsigned long long*)&long_lastp, blk_off.data(), &sum,
-                   (nlists % 3) ? 2048 : 0);                  // both staging sizes get exercised (same result either way)
-    hipsim::launch(k_gather, nlists < 8 ? nlists : 8, kThreads, (const unsigned long long*)cands.data(),
-                   (const int*)blk_count.data(), (const int*)blk_off.data(), nlists, rec_cap, sorted.data(), sorted_src.data());
+    OrderAcc acc{};
+    SIM_BY_MODE(mode, k_order, (nlists + kOrderLists - 1) / kOrderLists, kThreads, a, nlists, sorted.data(), sorted_src.data(), &sum, &acc);
     unsigned fmask = 0u, fwant = 0u;
     if (gate) {
       hipsim::launch(k_resolve, 3, kThreads, sorted.data(), (const Summary*)&sum, (long long)63 * sps,
@@ -138,7 +133,9 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     hipsim::launch(k_count, 3, kThreads, (const unsigned long long*)sorted.data(), (const Summary*)&sum, fmask, fwant,
                    head_n, seg.data());
     hipsim::launch(k_compact, 3, kThreads, (const unsigned long long*)sorted.data(), (const Rec*)recs.data(), (const unsigned*)sorted_src.data(), &sum,
-                   (const int*)seg.data(), fmask, fwant, head_n, outv.data(), (int)tot, &long_count, &long_lastp);
+                   (const int*)seg.data(), fmask, fwant, head_n, outv.data(), (int)tot, &long_count, &long_lastp, &acc, &sum_host);
+    if (acc.flags != 0u || acc.lastp_biased != 0ull) return -7;     // left clean for the slot's next pass
+    sum = sum_host;
     if (g_conf_out) SIM_BY_MODE(mode, k_confidence, 2, kThreads, a, (const Rec*)outv.data(), (const Summary*)&sum, (int)tot, g_conf_out);
   }
   so->n_rec = sum.n_rec; so->n_kept = sum.n_kept; so->overflow = sum.overflow; so->long_count = sum.long_count;

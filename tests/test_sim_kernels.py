@@ -321,6 +321,45 @@ def test_many_units():
     assert len(recs) > 200
 
 
+@pytest.mark.parametrize("mode", [1, 3])
+def test_ordering_kernel_over_several_workgroups_with_long_pulses(mode):
+    """k_order (round 4: long pulses + counts -> offsets + words into stream order in ONE launch) with more lists than one
+    of its workgroups owns (1024): 2600 lists = three workgroups, every one summing the counts in front of it itself; long
+    pulses (plateaus longer than k_detect's LDS window) planted in lists of the first, the second and the last workgroup,
+    one of them with a matching preamble behind it, so that each workgroup finishes its own placeholders before it reads
+    the list; and a call with no centre at all (empty lists everywhere).  Against the C oracle, bit for bit."""
+    n = 2600 * 1024 + 500
+    fs, sps = 2e6, 2
+    x = O.mag2(M.synth_iq(n, fs, 2500, seed=91)).copy()
+    env = M.burst_waveform(M.make_frame(17, np.random.default_rng(3)), sps)
+    for start, ln in ((300 * 1024 + 17, 1500), (1030 * 1024 + 999, 1281), (1500 * 1024 + 5, 3000), (2599 * 1024 - 700, 1400)):
+        x[start:start + ln] = 0.31
+        x[start + ln:start + ln + 40] = 0.0005                        # a quiet gap, then a reply right behind the plateau
+        x[start + ln + 40:start + ln + 40 + len(env)] = np.maximum(x[start + ln + 40:start + ln + 40 + len(env)], 0.5 * env)
+    # a long pulse that IS the first preamble pulse of a reply (centre matches: the record comes from global memory)
+    s0 = 2000 * 1024 + 333
+    x[s0 - 1400:s0 + 1] = 0.9
+    x[s0 + 1:s0 + 1 + len(env) - 1] = 0.0
+    # centre of [s0-1400, s0] is s0-700: plant the other preamble pulses relative to it
+    c = s0 - 700
+    x[c + 16:c + 16 + 240] = 0.0
+    if mode == 3:
+        q = M.quantize_iq8((np.sqrt(x) * np.exp(1j * 0.7)).astype(np.complex64), full_scale=4.0)
+        scale = float(np.float32(4.0 / 127.0))
+        data, kw = q, {"scale": scale}
+        xx = O.mag2_iq8(q, scale, False)
+    else:
+        data, kw, xx = x, {}, x
+    want = C.canonical(xx, sps, np.float32(0.01))
+    with simlib.tail_mode(1):
+        got, so = simlib.sim_canonical(mode, data, fs, 0.01, grid_max=650, **kw)
+        assert so.overflow == 0 and so.long_count >= 4
+        assert_recs_equal(got, want, "k_order, three workgroups")
+        assert len(got) > 2000
+        z, so = simlib.sim_canonical(1, np.zeros(1100 * 1024, np.float32), fs, 0.01, grid_max=650)
+        assert len(z) == 0 and so.n_rec == 0 and so.flags == 0 and so.lastp == -(1 << 62)
+
+
 @pytest.mark.parametrize("fs,bps,mode,grid_max", [(2e6, 4000, 0, 1), (8e6, 6000, 1, 2), (20e6, 9000, 3, 1), (2e6, 3000, 4, 2)])
 def test_bulk_pass_in_several_rounds_of_short_chunks(fs, bps, mode, grid_max):
     """A call with many more tiles than resident wavefronts is cut into up to eight rounds of chunks of four tiles or more

@@ -1131,6 +1131,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
       const int mx = body_commit<MODE, true>(body, s_x + kFwd, a.scale, lane, it < it_re ? nb : clamp);
       bool active = !thr_pos || __ballot(mx >= thr_bits) != 0ull;
       if (it >= it_rag) {
+        adsb_wave_sync();                                      // every lane's commit stores lie in front of the rewrite below
         for (int i = lane; i < kWTile; i += 64) s_x[kFwd + i] = xg<MODE>(cold()->data, cold()->n, t0 + kFwd + i, a.scale);
         active = true;
       }

@@ -471,10 +471,12 @@ def host_fed_all_ranks(args, fe, iq, depth, rank, n_gpus, sync_all, ag_obj):
     chunk = min(iq.shape[0], 1 << args.hostfed_log2n)
     reps, err, own, views = 12, None, float("nan"), None
     try:
-        pinned = [torch.empty((chunk, 2), dtype=torch.float32).pin_memory() for _ in range(3)]
+        # page-locked on the NUMA node of this rank's GPU (adsb_host_alloc_near): what a feeder's ring should be
+        pinned = [_native.PinnedArray(chunk, np.complex64, near=fe.ctx) for _ in range(3)]
+        src = iq[:chunk].cpu().numpy().view(np.complex64).reshape(-1)
         for p_ in pinned:
-            p_.copy_(iq[:chunk])
-        views = [p_.numpy().view(np.complex64).reshape(-1) for p_ in pinned]
+            p_.array[:] = src
+        views = [p_.array for p_ in pinned]
         for k in range(2):
             fe.ctx.wait(fe.ctx.submit_format_host(_native.FMT_FC32, views[k]), fetch=False)
     except Exception as e:                                       # noqa: BLE001
@@ -495,7 +497,9 @@ def host_fed_all_ranks(args, fe, iq, depth, rank, n_gpus, sync_all, ag_obj):
             err = "%s: %s" % (type(e).__name__, e)
     sync_all()
     wall = time.perf_counter() - t0
-    per = ag_obj({"rank": rank, "msamples_per_s": None if err else round(reps * chunk / own / 1e6, 1),
+    ni = fe.ctx.numa_info()
+    per = ag_obj({"rank": rank, "numa_node": ni["node"], "local_cpulist": ni["cpulist"], "pci": ni["pci"],
+                  "msamples_per_s": None if err else round(reps * chunk / own / 1e6, 1),
                   "gbytes_per_s": None if err else round(reps * chunk * 8 / own / 1e9, 2), "error": err})
     walls = ag_obj(wall)
     ok = all(r["error"] is None for r in per)
@@ -530,6 +534,10 @@ def main():
                     help="with --gpus N > 1: skip the PCIe-inclusive leg (every rank feeding its GPU from page-locked host memory)")
     ap.add_argument("--mixed-df", action="store_true",
                     help="BASELINE config 5's signal as the main workload: DF mix of docs/DF_histogram.txt, SNR 3-25 dB over noise 2e-3")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed the way an N-GPU launch does (backend cpu:gloo,cuda:nccl, RCCL barrier with "
+                         "its gloo fall-back) even with one rank, and let ranks share a GPU (rank r -> device r mod device_count): "
+                         "exercises the multi-GPU initialisation on a one-GPU box")
     ap.add_argument("--depth", type=int, default=0, help="passes in flight (default: the library's ADSB_MAX_IN_FLIGHT)")
     ap.add_argument("--low-latency", action="store_true", help="ADSB_FLAG_LOW_LATENCY: tail kernels beside the next pass's k_detect")
     ap.add_argument("--single-stream", action="store_true",
@@ -555,14 +563,18 @@ def main():
     # ADSB_BENCH_ONE_GPU=1: debugging aid -- run the N-rank code path with every rank on cuda:0 (gloo only)
     one_gpu = os.environ.get("ADSB_BENCH_ONE_GPU") == "1"
     host_group = None     # host-side collectives (mailbox set-up, object gathers, fallbacks): always gloo, never RCCL
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="gloo" if one_gpu else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
         host_group = dist.new_group(backend="gloo")
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
     n_gpus = world
     if one_gpu:
         local_rank = 0
+    elif args.force_dist:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -575,6 +587,20 @@ def main():
     stream_len = n_own * n_gpus
     fe = FrontEnd(fs, args.threshold, device=local_rank, timing=True,
                   flags=(_native.FLAG_SINGLE_STREAM if args.single_stream else 0) | (_native.FLAG_LOW_LATENCY if args.low_latency else 0))
+    # one process per GPU: run this rank's host side on the cpus local to its GPU (the library already places its pinned
+    # buffers and copy threads there, adsb_numa_info); a one-rank run stays wherever it was started
+    numa = fe.ctx.numa_info()
+    numa["bound"] = False
+    if n_gpus > 1 and numa["cpulist"] and hasattr(os, "sched_setaffinity"):
+        try:
+            cpus = set()
+            for part in numa["cpulist"].split(","):
+                a_, _, b_ = part.partition("-")
+                cpus.update(range(int(a_), int(b_ or a_) + 1))
+            os.sched_setaffinity(0, cpus & os.sched_getaffinity(0) or os.sched_getaffinity(0))
+            numa["bound"] = True
+        except (OSError, ValueError):
+            pass
 
     intfmt = args.format != "fc32"
     fmt = {"fc32": _native.FMT_FC32, "mag2": _native.FMT_MAG2, "sc16": _native.FMT_SC16, "sc8": _native.FMT_SC8,
@@ -650,7 +676,7 @@ def main():
     # barrier / max-over-ranks go over RCCL (backend "nccl") on the GPUs; if the communicator cannot be set up on
     # this node they fall back to the gloo side of the same process group rather than losing the run
     sync_dev = [dev]
-    if n_gpus > 1 and not one_gpu:
+    if dist_on and not one_gpu:
         try:
             probe = torch.zeros(1, device=dev)
             dist.all_reduce(probe)
@@ -667,12 +693,12 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if n_gpus > 1:
+        if dist_on:
             dist.all_reduce(torch.zeros(1, device=sync_dev[0]), group=sync_group())      # barrier
             torch.cuda.synchronize()
 
     def reduce_max(t):
-        if n_gpus == 1:
+        if not dist_on:
             return t
         tmax = torch.tensor([t], dtype=torch.float64, device=sync_dev[0])
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=sync_group())
@@ -711,9 +737,10 @@ def main():
               "ms_per_step_min": round(min(own_times) / args.steps * 1e3, 4), "ms_per_step_max": round(max(own_times) / args.steps * 1e3, 4),
               "kernel_ms": round(st["detect_ms"] / max(1, st["detect_launches"]), 4),
               "stitch_ms_per_step": round(host_t["stitch"] / max(1, args.steps * len(times) + args.warmup) * 1e3, 4),
-              "stitch_fallbacks": sharding.STATS["fallbacks"], "bursts_per_step": int(n_bursts)}
+              "stitch_fallbacks": sharding.STATS["fallbacks"], "bursts_per_step": int(n_bursts),
+              "numa_node": numa["node"], "local_cpulist": numa["cpulist"], "process_bound_to_local_cpus": numa["bound"]}
         per_rank = ag_obj(me)
-        if not one_gpu:
+        if not one_gpu and not args.force_dist:
             assert len({r["device"] for r in per_rank}) == n_gpus or len({r["pci_bus_id"] for r in per_rank}) == n_gpus, \
                 "ranks share a GPU (set ADSB_BENCH_ONE_GPU=1 if that is intended)"
         seam = seam_check(args, fe, dev, rank, n_gpus, sps, n_own, stream_len, last_kept[0], ag_obj)
@@ -752,12 +779,13 @@ def main():
                                "AWGN 2e-3" if args.mixed_df else "AWGN 1e-3", args.threshold, args.log2n),
                 "fs": fs, "samples_per_gpu_per_step": n_own, "bursts_per_step_rank0": int(n_bursts),
                 "sharding": "none" if n_gpus == 1 else "%d overlapped time shards, host stitch" % n_gpus,
-                "rank_sync": None if n_gpus == 1 else ("gloo" if sync_dev[0] == "cpu" else "rccl"),
+                "rank_sync": None if not dist_on else ("gloo" if sync_dev[0] == "cpu" else "rccl"),
                 "pipeline": "%d passes in flight (submit/wait)%s" % (DEPTH, (", single stream" if args.single_stream else "") + (", low-latency tail" if args.low_latency else "")),
                 "detect_gap_ms_avg": round(st["detect_gap_ms"] / max(1, st["detect_gaps"]), 4),
                 "detect_grid": int(st["detect_grid"]), "retries": int(st["retries"]), "longrun_calls": int(st["longrun_calls"]),
                 "long_pulses_per_step": round(st["longrun_pulses"] / max(1, st["calls"]), 2),
                 "env": env_known,
+                "numa_node": numa["node"], "local_cpulist": numa["cpulist"],
             },
             "roofline": roofline_of(st, args.format, iso_ms),
         }
@@ -839,6 +867,7 @@ def main():
     if n_gpus > 1:
         sync_all()
         ag_close()
+    if dist_on:
         dist.destroy_process_group()
     return result
 

@@ -19,6 +19,7 @@ FLAG_LONG_AWARE_GATE = 2  # opt-in: the gate holds 119*sps af
 FLAG_CONFIDENCE = 4       # opt-in: keep demod.bit_confidence's ratios (demod.py:97-101) for the whole-buffer entry points
 FLAG_SINGLE_STREAM = 8    # profiling aid: the sparse tail of a pass on the compute stream instead of beside the next pass
 FLAG_FRAMER_SLICES = 32   # adsb_framer_work also returns the 112 bits of tags whose burst ends inside the call's input
+FLAG_NO_NUMA_BINDING = 64 # host side not placed on the GPU's NUMA node (default: page-locked buffers and copy threads are)
 FLAG_LOW_LATENCY = 16     # the tail of a pass runs beside the next pass's k_detect: results a pass earlier, 1-2 % less throughput
 ABI_VERSION = 2
 # input sample formats (include/adsb_hip.h ADSB_FMT_*): numpy dtype of the flat host array, items per sample
@@ -43,7 +44,7 @@ EXPORTS = [
     "adsb_set_format_scale", "adsb_process_format", "adsb_process_format_device", "adsb_submit_format_device",
     "adsb_submit_format_host", "adsb_last_confidence",
     "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_shard_host", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_mode_s_syndrome", "adsb_plan_chunks", "adsb_get_stats",
-    "adsb_reset_stats", "adsb_detect_history", "adsb_last_error", "adsb_host_alloc", "adsb_host_free", "adsb_host_register", "adsb_host_unregister",
+    "adsb_reset_stats", "adsb_detect_history", "adsb_numa_info", "adsb_host_alloc_near", "adsb_last_error", "adsb_host_alloc", "adsb_host_free", "adsb_host_register", "adsb_host_unregister",
 ]
 
 
@@ -126,6 +127,8 @@ def load():
     lib.adsb_get_stats.argtypes = [vp, c.POINTER(Stats)]
     lib.adsb_reset_stats.argtypes = [vp]
     lib.adsb_detect_history.argtypes = [vp, vp, i32, c.POINTER(i32)]
+    lib.adsb_numa_info.argtypes = [vp, c.POINTER(i32), c.c_char_p, c.c_size_t, c.c_char_p, c.c_size_t]
+    lib.adsb_host_alloc_near.argtypes = [vp, c.POINTER(vp), c.c_size_t]
     lib.adsb_host_alloc.argtypes = [c.POINTER(vp), c.c_size_t]
     lib.adsb_host_free.argtypes = [vp]
     lib.adsb_host_register.argtypes = [vp, c.c_size_t]
@@ -380,6 +383,13 @@ class Context:
     def reset_stats(self):
         self._chk(self.lib.adsb_reset_stats(self._h))
 
+    def numa_info(self):
+        """{"node": NUMA node of the GPU's PCI device (-1 unknown / not bound), "cpulist": cpus local to it, "pci": address}."""
+        node = ctypes.c_int32(-1)
+        cl, bdf = ctypes.create_string_buffer(256), ctypes.create_string_buffer(32)
+        self._chk(self.lib.adsb_numa_info(self._h, ctypes.byref(node), cl, len(cl), bdf, len(bdf)))
+        return {"node": int(node.value), "cpulist": cl.value.decode(), "pci": bdf.value.decode()}
+
     def detect_history(self):
         """Per-launch k_detect durations (ms) since the last reset_stats, oldest first (FLAG_TIMING contexts)."""
         buf = np.zeros(4096, dtype=np.float32)
@@ -389,14 +399,18 @@ class Context:
 
 
 class PinnedArray:
-    """NumPy view of page-locked host memory from adsb_host_alloc (freed when this object dies)."""
+    """NumPy view of page-locked host memory from adsb_host_alloc (freed when this object dies); with `near=ctx` on the
+    NUMA node of that context's GPU (adsb_host_alloc_near)."""
 
-    def __init__(self, n, dtype):
+    def __init__(self, n, dtype, near=None):
         self.lib = load()
         self.dtype = np.dtype(dtype)
         self.nbytes = int(n) * self.dtype.itemsize
         self._p = ctypes.c_void_p()
-        rc = self.lib.adsb_host_alloc(ctypes.byref(self._p), max(1, self.nbytes))
+        if near is not None:
+            rc = self.lib.adsb_host_alloc_near(near._h, ctypes.byref(self._p), max(1, self.nbytes))
+        else:
+            rc = self.lib.adsb_host_alloc(ctypes.byref(self._p), max(1, self.nbytes))
         if rc != 0:
             raise AdsbError(rc, "adsb_host_alloc")
         buf = (ctypes.c_char * max(1, self.nbytes)).from_address(self._p.value)

@@ -26,6 +26,8 @@ from . import _native
 SYMBOL_RATE = 1e6
 NUM_PREAMBLE_BITS = 8
 MAX_NUM_BITS = 112
+_FEW = 6                                  # bursts per work() call up to which the per-burst scalar paths are used
+_F10, _F16, _INF = np.float32(10.0), np.float32(1.6), np.float32(np.inf)
 
 
 def make_pdu(start_timestamp, fs, offset, snr, bits112):
@@ -59,9 +61,11 @@ class _SliceStore:
     def __len__(self):
         return self._n
 
-    def put(self, offs, bits14, flags):
+    def put(self, offs, bits14, flags, offs_list=None):
+        """offs_list: the same offsets as a Python list, when the caller has it anyway (a scheduler-sized call with a
+        burst or two): take_few() then needs no NumPy call to find them."""
         with self._lock:
-            self._q.append((offs, bits14, flags))
+            self._q.append((offs, bits14, flags, offs_list))
             self._n += len(offs)
             while self._n > self.cap and len(self._q) > 1:
                 self._n -= len(self._q[0][0])
@@ -78,7 +82,7 @@ class _SliceStore:
         last = int(offs[-1])
         with self._lock:
             while self._q:
-                so, sb, sf = self._q[0]
+                so, sb, sf, _ = self._q[0]
                 i = np.searchsorted(so, offs)
                 hit = i < len(so)
                 hit[hit] = so[i[hit]] == offs[hit]
@@ -92,10 +96,42 @@ class _SliceStore:
                     continue
                 k = int(np.searchsorted(so, last, side="right"))
                 if k:                                       # the demod's chunk ended inside this framer call: keep the rest
-                    self._q[0] = (so[k:], sb[k:], sf[k:])
+                    self._q[0] = (so[k:], sb[k:], sf[k:], None)
                     self._n -= k
                 break
         return found, bits, flags
+
+    def take_few(self, offs):
+        """take() for a handful of tags (a scheduler-sized call: Python ints in, no NumPy arithmetic): offs is an increasing
+        list of ints; returns a list with, per tag, None or (bits14 row, flags).  Forgets like take()."""
+        res = [None] * len(offs)
+        last = offs[-1]
+        with self._lock:
+            while self._q:
+                so, sb, sf, sl = self._q[0]
+                if sl is None:
+                    sl = so.tolist()
+                for j, o in enumerate(offs):
+                    if res[j] is None and sl[0] <= o <= sl[-1]:
+                        try:
+                            i = sl.index(o)
+                        except ValueError:
+                            continue
+                        res[j] = (sb[i], int(sf[i]))
+                if sl[-1] <= last:                          # consumed to its end
+                    self._n -= len(sl)
+                    self._q.popleft()
+                    continue
+                k = 0
+                while sl[k] <= last:                        # (sl[-1] > last: terminates)
+                    k += 1
+                if k:
+                    self._q[0] = (so[k:], sb[k:], sf[k:], sl[k:])
+                    self._n -= k
+                else:
+                    self._q[0] = (so, sb, sf, sl)           # keep the list for the next call
+                break
+        return res
 
 
 class framer(gr.sync_block):
@@ -202,17 +238,38 @@ class framer(gr.sync_block):
         if self.improved:
             return self._work_improved(in0, out0)
         bursts = self._ctx.framer_work(in0[:N + self.N_hist - 1], N, self.nitems_written(0))
-        if len(bursts):                                   # (most scheduler-sized work() calls carry no burst)
-            snr = _native.snr_db(bursts["peak"], bursts["median"])
-            if self._paired:
-                dem = (bursts["flags"] & _native.BURST_DEMOD) != 0
-                if dem.any():
-                    self._slices.put(bursts["offset"][dem], bursts["bits"][dem], bursts["flags"][dem])
-            # one tag per burst is the only per-burst work the API forces (framer.py:168-174); everything else is arrays.
-            # real pmt.to_pmt wants Python floats; under the stand-in runtime the value stays np.float32 like the reference's
+        nb = len(bursts)
+        if nb:                                            # (most scheduler-sized work() calls carry no burst)
             key, src, add, to_pmt = self._pmt_key, self._pmt_src, self.add_item_tag, pmt.to_pmt
-            for off, s in zip(bursts["offset"].tolist(), snr.tolist() if HAVE_GNURADIO else list(snr)):
-                add(0, off, key, to_pmt(("SOB", s)), src)
+            # one tag per burst is the only per-burst work the API forces (framer.py:168-174).  real pmt.to_pmt wants Python
+            # floats; under the stand-in runtime the value stays np.float32 like the reference's
+            peak, med = bursts["peak"], bursts["median"]
+            if nb <= _FEW and bool(((med > 0) & (med < _INF)).all()) and bool((peak > 0).all()):
+                # a burst or two (a scheduler-sized call): scalar arithmetic, exactly the reference's own expression on
+                # np.float32 scalars (framer.py:157); no array temporaries, no errstate (nothing divides by zero here)
+                offs = bursts["offset"].tolist()
+                for j in range(nb):
+                    s_ = _F10 * np.log10(peak[j] / med[j]) + _F16
+                    add(0, offs[j], key, to_pmt(("SOB", float(s_) if HAVE_GNURADIO else s_)), src)
+                if self._paired:
+                    fl = bursts["flags"]
+                    if bool((fl & _native.BURST_DEMOD).all()):
+                        self._slices.put(bursts["offset"], bursts["bits"], fl, offs)
+                    else:
+                        dem = (fl & _native.BURST_DEMOD) != 0
+                        if dem.any():
+                            self._slices.put(bursts["offset"][dem], bursts["bits"][dem], fl[dem])
+            else:
+                snr = _native.snr_db(peak, med)
+                if self._paired:
+                    fl = bursts["flags"]
+                    dem = (fl & _native.BURST_DEMOD) != 0
+                    if dem.all():                         # the usual case: every burst ends inside the chunk
+                        self._slices.put(bursts["offset"], bursts["bits"], fl)
+                    elif dem.any():
+                        self._slices.put(bursts["offset"][dem], bursts["bits"][dem], fl[dem])
+                for off, s_ in zip(bursts["offset"].tolist(), snr.tolist() if HAVE_GNURADIO else list(snr)):
+                    add(0, off, key, to_pmt(("SOB", s_)), src)
         _passthrough(self._ctx, out0, in0[self.N_hist - 1:])
         return N
 
@@ -300,9 +357,25 @@ class demod(gr.sync_block):
         if self.improved:
             self._work_improved(in0, nread, tags)
         elif len(tags):
-            offs = np.fromiter((t.offset for t in tags), dtype=np.int64, count=len(tags))
             bits = None
-            if self._framer is not None and not self.want_confidence:
+            if self._framer is not None and not self.want_confidence and len(tags) <= _FEW:
+                # a tag or two (a scheduler-sized call): Python ints, no array arithmetic
+                offl = [t.offset for t in tags]
+                end = self.nitems_written(0) + len(in0) - (119 * self.sps + self.sps // 2)
+                got = self._framer._slices.take_few(offl)
+                if all((g is not None) or o >= end for g, o in zip(got, offl)):
+                    ok = np.array([o < end for o in offl], dtype=bool)
+                    bits = np.zeros((len(offl), 112), dtype=np.uint8)
+                    pf = np.zeros(len(offl), dtype=np.uint16)
+                    for j, g in enumerate(got):
+                        if g is not None and ok[j]:
+                            bits[j] = np.unpackbits(g[0])[:112]
+                            pf[j] = g[1]
+                    ratio = None
+                offs = None
+            else:
+                offs = np.fromiter((t.offset for t in tags), dtype=np.int64, count=len(tags))
+            if offs is not None and self._framer is not None and not self.want_confidence:
                 # bits the paired framer's pass already holds; this block's own drop rule (demod.py:76,82)
                 end = self.nitems_written(0) + len(in0)
                 ok = offs + (119 * self.sps + self.sps // 2) < end
@@ -311,6 +384,8 @@ class demod(gr.sync_block):
                     bits = np.unpackbits(b14, axis=1)[:, :112]       # ONE call for the whole chunk
                     ratio = None
             if bits is None:
+                if offs is None:
+                    offs = np.array(offl, dtype=np.int64)
                 # demod.py:79 indexes with nitems_written(0); equal to nitems_read(0) for this sync block
                 bits, ok, ratio = self._ctx.demod_work(in0, self.nitems_written(0), offs, want_ratio=self.want_confidence)
                 pf = self._ctx.last_demod_flags

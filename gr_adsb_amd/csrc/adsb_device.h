@@ -1621,7 +1621,23 @@ struct TailArgs {
   int* blk_off; int nblk, rec_cap; int* long_count; unsigned long long* long_lastp;
   unsigned long long* sorted; unsigned* sorted_src; int* seg_count; Summary* sum; Summary* host_sum; Rec* out; int out_cap;
   int gate_on, head_n; long long gate, gate_long, prev_eob;
+  int seq;               // this pass's number: stored LAST, into host_sum->pad_ -- the host polls it (adsb_hip.hip: finish)
 };
+// End of a one-workgroup pass: the summary into the caller-visible (pinned, mapped) host copy, then -- behind a system-scope
+// fence, so that the records compact_body stored straight into pinned host memory and the summary's fields are visible
+// first -- the pass number.  The host does not wait for the kernel's completion signal (end-of-kernel cache maintenance,
+// signal, the runtime's wake-up: several microseconds of a call that costs 25): it polls that word.
+__device__ __forceinline__ void publish_small(const TailArgs& t) {
+  if (threadIdx.x == 0) {
+    Summary f = *t.sum;
+    f.pad_ = 0;
+    Summary* h = t.host_sum;
+    h->n_rec = f.n_rec; h->n_kept = f.n_kept; h->overflow = f.overflow; h->long_count = f.long_count; h->flags = f.flags;
+    h->lastp = f.lastp; h->last_kept_p = f.last_kept_p;
+    __threadfence_system();
+    *reinterpret_cast<volatile int*>(&h->pad_) = t.seq;
+  }
+}
 template <int MODE>
 __global__ void __launch_bounds__(kThreads) k_tail_small(DetectArgs a, TailArgs t) {
   longrun_body<MODE>(0, 1, a);                                // pulses longer than k_detect's LDS window (usually none)
@@ -1642,7 +1658,7 @@ __global__ void __launch_bounds__(kThreads) k_tail_small(DetectArgs a, TailArgs 
   compact_body(0, 1, t.sorted, t.recs, t.sorted_src, t.sum, t.seg_count, fmask, fwant, t.head_n, t.out, t.out_cap, t.long_count,
                t.long_lastp);
   __syncthreads();
-  if (threadIdx.x == 0) *t.host_sum = *t.sum;
+  publish_small(t);
 }
 
 // ---- k_pass_small: a WHOLE small pass -- the one pass over the samples and its tail -- in one workgroup and ONE launch.
@@ -1672,7 +1688,7 @@ __global__ void __launch_bounds__(kThreads) k_pass_small(DetectArgs a, TailArgs 
   compact_body(0, 1, t.sorted, t.recs, t.sorted_src, t.sum, t.seg_count, fmask, fwant, t.head_n, t.out, t.out_cap, t.long_count,
                t.long_lastp);
   __syncthreads();
-  if (threadIdx.x == 0) *t.host_sum = *t.sum;
+  publish_small(t);
 }
 
 // ---- k_slice: PPM slice (+ optional confidence ratio) for a caller-supplied tag list ---------------

@@ -7,11 +7,18 @@
 // The library reads no environment variable.
 #include <hip/hip_runtime.h>
 
+#include <pthread.h>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -186,6 +193,8 @@ struct Slot {
   bool fused = false;            // ... and the whole pass is ONE launch (k_pass_small)
   bool is_shard = false;
   bool ev1_valid = false;
+  int seq = 0;                   // direct passes: the number the kernel stores into h_sum->pad_ when everything is out
+  bool polled = false;           // ... and finish() polls for instead of waiting for an event
   Plan plan{};
   DetectArgs args{};
   int grid = 0, nlists = 0, rec_cap = 0;
@@ -209,6 +218,8 @@ struct CopyPool {
   int pending = 0;
   bool stop = false;
   int nthreads = 0;      // workers besides the caller
+  cpu_set_t cpus;        // the host cpus local to the context's GPU (NUMA node of its PCI device); workers run there
+  bool have_cpus = false;
 
   static void slice(size_t bytes, int parts, int i, size_t* lo, size_t* hi) {
     const size_t per = ((bytes / (size_t)parts) + 4095) & ~(size_t)4095;
@@ -233,7 +244,12 @@ struct CopyPool {
   }
   void start(int n) {
     nthreads = n;
-    for (int i = 0; i < n; ++i) th.emplace_back([this, i] { worker(i); });
+    for (int i = 0; i < n; ++i) {
+      th.emplace_back([this, i] { worker(i); });
+      // the copy of a pageable source into the pinned ring is bound by host memory bandwidth: keep it on the socket the
+      // ring lives on and the GPU hangs off (best effort: an error leaves the thread where the scheduler puts it)
+      if (have_cpus) (void)pthread_setaffinity_np(th.back().native_handle(), sizeof(cpus), &cpus);
+    }
   }
   // blocking: returns when all of [src, src + bytes) is in dst
   void copy(char* d_, const char* s_, size_t b_) {
@@ -294,6 +310,12 @@ struct adsb_ctx {
   hipEvent_t ring_done[kRing] = {nullptr, nullptr, nullptr, nullptr};
   bool ring_used[kRing] = {false, false, false, false};
   unsigned ring_k = 0;
+  // NUMA placement of the host side (adsb_numa_info): the node and cpus local to the GPU's PCI device, from sysfs
+  int numa_node = -1;
+  char pci_bdf[32] = {0};
+  char cpulist[256] = {0};
+  cpu_set_t local_cpus;
+  bool have_local_cpus = false;
   CopyPool* pool = nullptr;    // host copy threads of the pageable path (adsb_set_copy_threads; created on first use)
   int copy_threads = -1;       // -1 = default
   adsb_stats stats{};
@@ -329,11 +351,70 @@ int ensure(adsb_ctx* c, DevBuf& b, size_t bytes) {
   return 0;
 }
 
+// Page-locked host memory on the NUMA node of the context's GPU: the calling thread's memory policy is set to prefer that
+// node for the duration of the allocation (raw set_mempolicy: no libnuma in the image) and hipHostMallocNumaUser tells HIP
+// to honour it.  Without a known node (numa_node < 0: single-socket host, or sysfs not visible) a plain allocation.
+constexpr int kMpolDefault = 0, kMpolPreferred = 1;
+hipError_t host_alloc_near(adsb_ctx* c, void** p, size_t bytes) {
+  if (!c || c->numa_node < 0 || c->numa_node >= 1024) return hipHostMalloc(p, bytes, hipHostMallocDefault);
+  unsigned long mask[16] = {0};
+  mask[c->numa_node / (8 * sizeof(unsigned long))] |= 1ul << (c->numa_node % (8 * sizeof(unsigned long)));
+  const long rc = syscall(SYS_set_mempolicy, kMpolPreferred, mask, sizeof(mask) * 8);
+  hipError_t e = hipHostMalloc(p, bytes, rc == 0 ? hipHostMallocNumaUser : hipHostMallocDefault);
+  if (rc == 0) (void)syscall(SYS_set_mempolicy, kMpolDefault, nullptr, 0);
+  if (e != hipSuccess && rc == 0) { (void)hipGetLastError(); e = hipHostMalloc(p, bytes, hipHostMallocDefault); }
+  return e;
+}
+
+// "0-63,128-191" -> cpu set
+bool parse_cpulist(const char* sl, cpu_set_t* set) {
+  CPU_ZERO(set);
+  int any = 0;
+  const char* p = sl;
+  while (*p) {
+    char* e = nullptr;
+    long a = strtol(p, &e, 10);
+    if (e == p) break;
+    long b = a;
+    p = e;
+    if (*p == '-') { b = strtol(p + 1, &e, 10); if (e == p + 1) break; p = e; }
+    for (long k = a; k <= b && k < CPU_SETSIZE; ++k) { if (k >= 0) { CPU_SET((int)k, set); ++any; } }
+    if (*p == ',') ++p; else break;
+  }
+  return any > 0;
+}
+
+bool read_line(const char* path, char* out, size_t cap) {
+  FILE* f = fopen(path, "r");
+  if (!f) return false;
+  const bool ok = fgets(out, (int)cap, f) != nullptr;
+  fclose(f);
+  if (ok) { size_t n = strlen(out); while (n && (out[n - 1] == '\n' || out[n - 1] == ' ')) out[--n] = 0; }
+  return ok;
+}
+
+// numa_node / local_cpulist of the GPU's PCI device (/sys/bus/pci/devices/<bdf>/): which host memory and which cpus are
+// local to it.  Best effort: a container may hide sysfs, a single-socket host reports node -1 or 0.
+void probe_numa(adsb_ctx* c) {
+  char bdf[32] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), c->device) != hipSuccess) { (void)hipGetLastError(); return; }
+  for (char* q = bdf; *q; ++q) if (*q >= 'A' && *q <= 'F') *q = (char)(*q - 'A' + 'a');      // sysfs spells it in lower case
+  snprintf(c->pci_bdf, sizeof(c->pci_bdf), "%s", bdf);
+  char path[128], line[256];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+  if (read_line(path, line, sizeof(line))) c->numa_node = atoi(line);
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+  if (read_line(path, line, sizeof(line)) && line[0]) {
+    snprintf(c->cpulist, sizeof(c->cpulist), "%s", line);
+    c->have_local_cpus = parse_cpulist(line, &c->local_cpus);
+  }
+}
+
 int ensure_pinned(adsb_ctx* c, void*& p, size_t& cap, size_t bytes) {
   if (bytes <= cap) return 0;
   if (p) { HIPCHK(c, hipHostFree(p)); p = nullptr; cap = 0; }
   size_t want = bytes + bytes / 4 + 4096;
-  HIPCHK(c, hipHostMalloc(&p, want, hipHostMallocDefault));
+  HIPCHK(c, host_alloc_near(c, &p, want));
   cap = want;
   return 0;
 }
@@ -417,9 +498,12 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
     t.seg_count = (int*)s.d_seg.p; t.sum = &misc->sum; t.host_sum = s.h_sum; t.out = (Rec*)s.h_out; t.out_cap = (int)s.tot;
     t.gate_on = pl.gate ? 1 : 0; t.head_n = pl.head_n; t.gate = 63ll * c->sps;
     t.gate_long = (long long)(pl.long_aware ? 119 : 63) * c->sps; t.prev_eob = pl.prev_eob_stream - pl.origin;
+    s.seq = s.seq >= 0x7FFFFFF0 ? 1 : s.seq + 1;
+    t.seq = s.seq;
     if (s.fused) launch_pass_small(ts, a, t);
     else ADSB_BY_MODE(pl.mode, launch_tail_small, ts, a, t);
-    HIPCHK(c, hipEventRecord(s.done, ts));
+    // the host polls the pass number in the pinned summary (finish): no completion event on the stream
+    s.polled = true;
     return 0;
   }
   if (c->split_tail) {
@@ -532,6 +616,7 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   c->stats.calls++;
   s.busy = true;
   s.ev1_valid = timing;
+  s.polled = false;
   return enqueue_tail(c, s);
 }
 
@@ -547,8 +632,26 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
   FINCHK(hipSetDevice(c->device));
   const bool timing = (c->flags & ADSB_FLAG_TIMING) != 0;
   for (int attempt = 0; attempt < 16; ++attempt) {
-    FINCHK(hipEventSynchronize(s.done));
-    FINCHK(hipGetLastError());
+    if (s.polled) {
+      // a one-workgroup pass: its last store is the pass number (publish_small); spin on it -- bounded: a kernel that died
+      // never stores it, and the stream synchronisation below reports why
+      const volatile int* seqp = &s.h_sum->pad_;
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (*seqp != s.seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if (*seqp != s.seq) {
+        FINCHK(hipStreamSynchronize(c->stream));
+        FINCHK(hipGetLastError());
+        if (*seqp != s.seq) { s.busy = false; return fail(c, -EIO, "small pass finished without publishing its summary"); }
+      }
+    } else {
+      FINCHK(hipEventSynchronize(s.done));
+      FINCHK(hipGetLastError());
+    }
     if (timing) {
       float ms = 0;
       FINCHK(hipEventElapsedTime(&ms, s.ev0, s.ev1));
@@ -668,6 +771,7 @@ int ensure_pool(adsb_ctx* c) {
   if (!c->pool) return fail(c, -ENOMEM, "copy pool");
   const unsigned hw = std::thread::hardware_concurrency();
   const int nt = c->copy_threads >= 0 ? c->copy_threads : (hw >= 16 ? 5 : (hw >= 4 ? 2 : 0));     // workers besides the caller
+  if (c->have_local_cpus && !(c->flags & ADSB_FLAG_NO_NUMA_BINDING)) { c->pool->cpus = c->local_cpus; c->pool->have_cpus = true; }
   c->pool->start(nt);
   return 0;
 }
@@ -677,7 +781,7 @@ int ensure_pool(adsb_ctx* c) {
 int staged_copy(adsb_ctx* c, void* d_dst, const void* host, size_t bytes, hipStream_t stream) {
   constexpr size_t kChunk = (size_t)16 << 20;
   for (void*& r : c->h_ring)
-    if (!r) HIPCHK(c, hipHostMalloc(&r, kChunk, hipHostMallocDefault));
+    if (!r) HIPCHK(c, host_alloc_near(c, &r, kChunk));          // the staging ring: on the GPU's NUMA node
   int rc = ensure_pool(c);
   if (rc) return rc;
   for (size_t off = 0; off < bytes; off += kChunk) {
@@ -779,6 +883,8 @@ int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx
   if (hipSetDevice(device) != hipSuccess) { delete c; return -ENODEV; }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+  probe_numa(c);
+  if (flags & ADSB_FLAG_NO_NUMA_BINDING) c->numa_node = -1;    // (the cpu list stays readable through adsb_numa_info)
   {
     int nb;
     if ((nb = detect_occupancy<0>(c->det_dyn_lds[0])) > 0) c->bpc[0] = nb;
@@ -804,7 +910,8 @@ int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx
   for (hipEvent_t& e : c->ring_done)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { adsb_destroy(c); return -EIO; }
   for (Slot& sl : c->slot) {
-    if (hipHostMalloc((void**)&sl.h_sum, sizeof(Summary), hipHostMallocDefault) != hipSuccess) { adsb_destroy(c); return -ENOMEM; }
+    if (host_alloc_near(c, (void**)&sl.h_sum, sizeof(Summary)) != hipSuccess) { adsb_destroy(c); return -ENOMEM; }
+    memset(sl.h_sum, 0, sizeof(Summary));                        // (pad_ is the pass number finish() polls: starts at zero)
     if (hipEventCreate(&sl.ev0) != hipSuccess || hipEventCreate(&sl.ev1) != hipSuccess ||
         hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&sl.det_done, hipEventDisableTiming) != hipSuccess ||
@@ -868,6 +975,20 @@ int adsb_set_copy_threads(adsb_ctx* c, int32_t threads) {
   if (c->pool) return fail(c, -EBUSY, "copy threads already running (set before the first pageable submission)");
   c->copy_threads = threads - 1;                            // the calling thread is one of them
   return 0;
+}
+
+int adsb_numa_info(adsb_ctx* c, int32_t* node, char* cpulist, size_t cap, char* pci_bdf, size_t bdf_cap) {
+  if (!c) return -EINVAL;
+  if (node) *node = c->numa_node;
+  if (cpulist && cap) snprintf(cpulist, cap, "%s", c->cpulist);
+  if (pci_bdf && bdf_cap) snprintf(pci_bdf, bdf_cap, "%s", c->pci_bdf);
+  return 0;
+}
+
+int adsb_host_alloc_near(adsb_ctx* c, void** p, size_t bytes) {
+  if (!c || !p || bytes == 0) return -EINVAL;
+  *p = nullptr;
+  return host_alloc_near(c, p, bytes) == hipSuccess ? 0 : -ENOMEM;
 }
 
 int adsb_host_copy(adsb_ctx* c, void* dst, const void* src, size_t bytes) {

@@ -75,6 +75,12 @@ extern "C" {
  * come back with ADSB_BURST_DEMOD, bits and the parity pre-filter flags -- the one device pass a framer/demod pair of
  * one flowgraph needs (gr_adsb_amd.blocks.demod(fs, framer=...)); default off: tags carry offset / peak / median only. */
 #define ADSB_FLAG_FRAMER_SLICES 32u
+/* Host-side NUMA placement is ON by default: the context looks up the NUMA node and the cpus local to its GPU's PCI device
+ * (/sys/bus/pci/devices/<bdf>/numa_node, local_cpulist), allocates its page-locked buffers (staging ring, result and
+ * summary buffers) on that node and runs its copy threads on those cpus -- on a two-socket 8-GPU node (one process per GPU,
+ * SURVEY.md §8e) half of the host-fed traffic would otherwise cross the socket interconnect.  This flag turns it off
+ * (adsb_numa_info still reports what was found).  No reference counterpart: the reference is one Python thread. */
+#define ADSB_FLAG_NO_NUMA_BINDING 64u
 
 /* adsb_burst.flags */
 #define ADSB_BURST_DEMOD 1u /* eob inside the demod input: bits[] valid, a PDU is published (demod.py:82) */
@@ -166,6 +172,13 @@ int adsb_process_mag2(adsb_ctx* ctx, const float* mag2_host, int64_t n, int64_t 
  * buffers are first copied into the context's own pinned staging buffer (about 3x slower end to end). */
 int adsb_host_alloc(void** p, size_t bytes);
 int adsb_host_free(void* p);
+/* The same on the NUMA node of the context's GPU (see ADSB_FLAG_NO_NUMA_BINDING): what a feeder should fill its IQ ring
+ * from, so that the H2D DMA reads local memory.  Freed with adsb_host_free. */
+int adsb_host_alloc_near(adsb_ctx* ctx, void** p, size_t bytes);
+/* Where the context's host side lives: NUMA node of the GPU's PCI device (-1: unknown / not bound), the cpus local to it
+ * as sysfs prints them ("0-63,128-191", "" if unknown) and the device's PCI address ("0000:c1:00.0").  Any pointer may be
+ * null.  For reports (bench.py prints it per rank) and for callers that want to pin their own feeder threads. */
+int adsb_numa_info(adsb_ctx* ctx, int32_t* node, char* cpulist, size_t cpulist_cap, char* pci_bdf, size_t bdf_cap);
 /* Page-lock a buffer the caller already owns (e.g. the ring an SDR driver or a file mapping fills), so that
  * adsb_process_* / adsb_submit_format_host DMA it where it lies instead of copying it through the context's staging
  * chunks (about half the rate).  Registration costs milliseconds: do it once per buffer, not per call; unregister before

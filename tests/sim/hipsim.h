@@ -259,5 +259,6 @@ template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; 
 template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 inline void __threadfence() {}
+inline void __threadfence_system() {}
 // the kernel's argument block "as it lies in memory": for the emulator simply the by-value copy
 template <class A> inline const A* adsb_cold(const A& a) { return &a; }

@@ -108,6 +108,7 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     t.seg_count = seg.data(); t.sum = &sum; t.host_sum = &sum_host; t.out = outv.data(); t.out_cap = (int)tot;
     t.gate_on = gate ? 1 : 0; t.head_n = head_n; t.gate = 63ll * sps; t.gate_long = (long long)(g_long_aware ? 119 : 63) * sps;
     t.prev_eob = prev_eob_stream - origin;
+    t.seq = 7;
     if (one_launch) {
       switch (sps) {
         case 2: hipsim::launch(k_pass_small<1>, 1, kThreads, a, t); break;
@@ -119,6 +120,7 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     } else {
       SIM_BY_MODE(mode, k_tail_small, 1, kThreads, a, t);
     }
+    if (sum_host.pad_ != 7) return -8;               // the pass number the host polls for
     sum = sum_host;
     if (g_conf_out) SIM_BY_MODE(mode, k_confidence, 2, kThreads, a, (const Rec*)outv.data(), (const Summary*)&sum, (int)tot, g_conf_out);
   } else {

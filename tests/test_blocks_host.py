@@ -29,6 +29,36 @@ def test_slice_store_hands_over_in_stream_order_and_forgets_what_was_asked_for()
     assert found.tolist() == [False, False, True] and len(st) == 0
 
 
+def test_slice_store_take_few_matches_take():
+    """take_few (the Python-int path of a scheduler-sized call) and take (the array path) are the same hand-over: same rows,
+    same forgetting, and entries written by either kind of put() serve either kind of take."""
+    rng = np.random.default_rng(3)
+    offs_all = np.cumsum(rng.integers(1, 50, 400))
+    for mode in range(3):
+        a, b = _SliceStore(cap=10000), _SliceStore(cap=10000)
+        pos = 0
+        while pos < len(offs_all):
+            k = int(rng.integers(1, 9))
+            chunk = offs_all[pos:pos + k]
+            for st in (a, b):
+                st.put(*_call(chunk), chunk.tolist() if (mode + pos) % 2 else None)
+            pos += k
+        pos = 0
+        while pos < len(offs_all):
+            k = int(rng.integers(1, 7))
+            want = offs_all[pos:pos + k].copy()
+            if mode == 2 and len(want) > 1:
+                want[0] -= 1 if pos and want[0] - 1 != offs_all[pos - 1] else 0     # a tag the framer had no bits for
+            found, bits, flags = a.take(want.astype(np.int64))
+            few = b.take_few(want.tolist())
+            assert [g is not None for g in few] == found.tolist()
+            for j, g in enumerate(few):
+                if g is not None:
+                    assert np.array_equal(g[0], bits[j]) and g[1] == int(flags[j])
+            assert len(a) == len(b)
+            pos += k
+
+
 def test_slice_store_under_two_threads():
     """put() on one thread, take() on another (blocks.py: framer.work / demod.work under GNU Radio's scheduler): every row
     handed over is the row that was stored, nothing raises, and whatever was not found had been evicted or not yet stored."""

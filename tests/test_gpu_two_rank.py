@@ -135,3 +135,58 @@ def test_bench_two_ranks_one_gpu_seam_check():
     assert mg["ranks_seen"] == 2 and mg["exchange_transport"] == "shm mailbox"
     assert mg["seam_check"]["all_identical"] and mg["seam_check"]["per_seam"][0]["bursts_compared"] > 100
     assert [r_["rank"] for r_ in mg["per_rank"]] == [0, 1]
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_bench_force_dist_initialises_like_a_multi_gpu_launch(world):
+    """bench.py --force-dist: the process group is created the way an N-GPU launch creates it (backend cpu:gloo,cuda:nccl),
+    the barrier / max-over-ranks try RCCL first and fall back to the gloo side when the communicator cannot be built.  On
+    this one-GPU box: one rank -> RCCL works (a communicator of one); two ranks sharing cuda:0 -> RCCL refuses the duplicate
+    device and the gloo fall-back carries the run.  Either way the line is complete and, with two ranks, the seam between
+    the two shards compares identical to a canonical call."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("ADSB_BENCH_ONE_GPU", None)
+    tail = ["--gpus", str(world), "--force-dist", "--steps", "4", "--warmup", "1", "--log2n", "23", "--min-time", "0.05",
+            "--no-cpu", "--no-extra", "--no-hostfed", "--no-host-fed-multi"]
+    port = str(_free_port())
+    if world == 1:
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+               "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py")] + tail
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == world and d["value"] > 0
+    assert d["config"]["rank_sync"] in ("rccl", "gloo")
+    if world == 1:
+        assert d["config"]["rank_sync"] == "rccl", "a communicator of one rank must come up on the GPU box"
+    else:
+        assert d["multi_gpu"]["seam_check"]["all_identical"]
+        assert all("numa_node" in r_ and "local_cpulist" in r_ for r_ in d["multi_gpu"]["per_rank"])
+    assert "numa_node" in d["config"]
+
+
+def test_numa_placement_is_reported_and_allocations_work():
+    """adsb_numa_info / adsb_host_alloc_near: the context reports the NUMA node and cpus of its GPU's PCI device (what sysfs
+    says; -1 / "" where sysfs is hidden), page-locked memory allocated near the GPU is DMA'd in place by the host-fed path,
+    and the results equal a blocking call's."""
+    from gr_adsb_amd import _native
+    from gr_adsb_amd import modulator as M
+    ctx = _native.Context(2e6, 0.01)
+    info = ctx.numa_info()
+    assert set(info) == {"node", "cpulist", "pci"} and info["node"] >= -1
+    path = "/sys/bus/pci/devices/%s/numa_node" % info["pci"]
+    if info["pci"] and os.path.exists(path):
+        assert info["node"] == int(open(path).read())
+        assert info["cpulist"] == open(os.path.dirname(path) + "/local_cpulist").read().strip()
+    iq = M.synth_iq(1 << 20, 2e6, 3000, seed=5)
+    near = _native.PinnedArray(len(iq), np.complex64, near=ctx)
+    near.array[:] = iq
+    got = ctx.wait(ctx.submit_format_host(_native.FMT_FC32, near.array))
+    want = _native.Context(2e6, 0.01, flags=_native.FLAG_NO_NUMA_BINDING).process_iq(iq)
+    assert len(want) > 500 and got.tobytes() == want.tobytes()
+    pageable = ctx.wait(ctx.submit_format_host(_native.FMT_FC32, np.tile(iq, 8)))       # 64 MB: the copy threads and the ring
+    assert len(pageable) > 8 * 500
+    ctx.close()

@@ -86,3 +86,40 @@ if "--profile" in sys.argv:
         fr.tags_out.clear()
         dm.messages.clear()
     pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+
+if "--small" in sys.argv:
+    # where a scheduler-sized call's time goes: the C entry point alone (ctypes call included), the block's work() around
+    # it, the paired demod with and without a tag in the chunk
+    from gr_adsb_amd import _native
+    N = 2048
+    ctx = _native.Context(fs, 0.01, flags=_native.FLAG_FRAMER_SLICES)
+    quiet = np.full(N + H - 1, 1e-4, np.float32)
+    busy = buf[:N + H - 1].copy()
+    for name, arr in (("quiet chunk", quiet), ("chunk of the test stream", busy)):
+        for _ in range(200):
+            ctx.framer_work(arr, N, 0)
+        t0 = time.perf_counter()
+        for _ in range(2000):
+            ctx.framer_work(arr, N, 0)
+        print("adsb_framer_work through ctypes, %-26s %.2f us per call" % (name + ":", (time.perf_counter() - t0) / 2000 * 1e6))
+    fr = blocks.framer(fs, 0.01)
+    dm = blocks.demod(fs, framer=fr)
+    out = np.empty(N, np.float32)
+    for name, arr in (("quiet chunk", quiet), ("chunk of the test stream", busy)):
+        tf = td = 0.0
+        for k in range(2200):
+            fr._nread = fr._nwritten = 0
+            t1 = time.perf_counter()
+            fr.work([arr], [out])
+            t2 = time.perf_counter()
+            dm.tags_in = list(fr.tags_out)
+            dm._nread = dm._nwritten = 0
+            t3 = time.perf_counter()
+            dm.work([arr[H - 1:]], [out])
+            t4 = time.perf_counter()
+            if k >= 200:
+                tf += t2 - t1
+                td += t4 - t3
+            fr.tags_out.clear()
+            dm.messages.clear()
+        print("blocks, %-26s framer.work %.2f us, paired demod.work %.2f us" % (name + ":", tf / 2000 * 1e6, td / 2000 * 1e6))

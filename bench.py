@@ -334,7 +334,7 @@ def format_legs(args, dev, depth):
     torch.cuda.synchronize()
     out = []
     for name, fmt, scale in (("mag2", _native.FMT_MAG2, None), ("sc16", _native.FMT_SC16, 4.0 / 32767.0),
-                             ("sc8", _native.FMT_SC8, 4.0 / 127.0), ("cu8", _native.FMT_CU8, 4.0 / 255.0)):
+                             ("sc8", _native.FMT_SC8, 4.0 / 128.0), ("cu8", _native.FMT_CU8, 4.0 / 255.0)):
         fe = FrontEnd(fs, args.threshold, device=dev.index, timing=True)
         q = quantise_for(fmt, base, fe)
         torch.cuda.synchronize()
@@ -372,8 +372,10 @@ def quantise_for(fmt, iq, fe):
         fe.ctx.set_format_scale(fmt, 4.0 / 32767.0)
         return torch.clamp(torch.round(iq * (32767.0 / 4.0)), -32768, 32767).to(torch.int16).contiguous()
     if fmt == _native.FMT_SC8:
-        fe.ctx.set_format_scale(fmt, 4.0 / 127.0)
-        return torch.clamp(torch.round(iq * (127.0 / 4.0)), -128, 127).to(torch.int8).contiguous()
+        # the usual int8 convention, component = i8 * 2^-k (here full scale 4.0: 2^-5): a power-of-two scale also selects
+        # the library's dot-product instance of k_detect (adsb_hip.hip: launch_detect)
+        fe.ctx.set_format_scale(fmt, 4.0 / 128.0)
+        return torch.clamp(torch.round(iq * (128.0 / 4.0)), -128, 127).to(torch.int8).contiguous()
     if fmt == _native.FMT_CU8:
         fe.ctx.set_format_scale(fmt, 4.0 / 255.0)
         return torch.clamp(torch.floor(iq * (127.5 / 4.0) + 128.0), 0, 255).to(torch.uint8).contiguous()

@@ -45,6 +45,8 @@ __device__ __forceinline__ int adsb_opaque(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
+// sum of the four products of the signed bytes of a and b (v_dot4_i32_i8)
+__device__ __forceinline__ int adsb_sdot4(int a, int b) { return __builtin_amdgcn_sdot4(a, b, 0, false); }
 // streamed single-use data: non-temporal load (every sample is fetched exactly once)
 template <class Q>
 __device__ __forceinline__ Q adsb_ld_stream(const char* p) {
@@ -431,16 +433,28 @@ int ensure_pinned(adsb_ctx* c, void*& p, size_t& cap, size_t bytes) {
 
 // k_detect is instantiated per input format and per samples-per-chip of the common rates (2, 4, 8, 20 Msps: the
 // preamble taps become immediate offsets); any other even rate runs the run-time-stride instance
+template <int KMODE>
+void launch_detect_k(adsb_ctx* c, unsigned dyn, const DetectArgs& a, int grid) {
+  switch (a.sps) {
+    case 2: hipLaunchKernelGGL((k_detect<KMODE, 1>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
+    case 4: hipLaunchKernelGGL((k_detect<KMODE, 2>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
+    case 8: hipLaunchKernelGGL((k_detect<KMODE, 4>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
+    case 20: hipLaunchKernelGGL((k_detect<KMODE, 10>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
+    default: hipLaunchKernelGGL((k_detect<KMODE, 0>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
+  }
+}
+// a power of two whose square, times any integer below 2^15, is an exact float32: what the int8 dot-product instance needs
+bool scale_is_pow2(float s) {
+  int e = 0;
+  const float m = frexpf(s, &e);
+  return m == 0.5f && e > -50 && e < 50;
+}
 template <int MODE>
 void launch_detect(adsb_ctx* c, const DetectArgs& a, int grid) {
   const unsigned dyn = c->det_dyn_lds[MODE];
-  switch (a.sps) {
-    case 2: hipLaunchKernelGGL((k_detect<MODE, 1>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
-    case 4: hipLaunchKernelGGL((k_detect<MODE, 2>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
-    case 8: hipLaunchKernelGGL((k_detect<MODE, 4>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
-    case 20: hipLaunchKernelGGL((k_detect<MODE, 10>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
-    default: hipLaunchKernelGGL((k_detect<MODE, 0>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
-  }
+  // int8 IQ with a power-of-two scale (x / 128 and the like): the instance whose tile loop squares with v_dot4_i32_i8
+  if (MODE == ADSB_FMT_SC8 && scale_is_pow2(a.scale)) launch_detect_k<kModeSc8Pow2>(c, dyn, a, grid);
+  else launch_detect_k<MODE>(c, dyn, a, grid);
 }
 template <int MODE>
 unsigned detect_static_lds() {

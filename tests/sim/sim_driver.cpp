@@ -89,11 +89,15 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     case 20: hipsim::launch(k_detect<MODE, 10>, grid, kThreads, a); break;                 \
     default: hipsim::launch(k_detect<MODE, 0>, grid, kThreads, a); break;                  \
   }
-  if (!one_launch) switch (mode) {
+  // like adsb_hip.hip: launch_detect(): int8 IQ with a power-of-two scale runs the dot-product instance
+  int fe = 0;
+  const bool pow2 = mode == 3 && frexpf(scale, &fe) == 0.5f && fe > -50 && fe < 50;
+  if (!one_launch) switch (pow2 ? 5 : mode) {
     case 0: SIM_DETECT(0) break;
     case 1: SIM_DETECT(1) break;
     case 2: SIM_DETECT(2) break;
     case 3: SIM_DETECT(3) break;
+    case 5: SIM_DETECT(5) break;
     default: SIM_DETECT(4) break;
   }
 #undef SIM_DETECT

@@ -190,7 +190,7 @@ def test_kernel_resources_keep_the_tail_co_resident():
     LDS_CU, VGPR_SIMD, WG = 160 * 1024, 512, 5
     alloc = lambda v: -(-v // 8) * 8                                    # noqa: E731  (allocation granule: 8 VGPRs)
     detect = {k: v for k, v in res.items() if "k_detect" in k}
-    assert len(detect) == 25                                            # 5 input formats x 5 samples-per-chip instances
+    assert len(detect) == 30            # (5 input formats + int8 with a power-of-two scale) x 5 samples-per-chip instances
     tail = {k: v for k, v in res.items() if any(t in k for t in ("k_order", "k_resolve", "k_count", "k_compact"))}
     assert len(tail) == 8                                               # k_order per input format + three format-blind kernels
     for name, d in detect.items():

@@ -633,13 +633,13 @@ def main():
             # kernels of the next; every pass is collected inside the timed region (drain() below)
             pending.append(fe.submit_format_tensor(fmt, iq, 0))
             if len(pending) == DEPTH:
-                return fe.wait(pending.pop(0), fetch=False)
+                last_n[0] = fe.wait(pending.pop(0), fetch=False)
             return 0
         # N>1: same DEPTH-deep pipeline; the host stitch of pass i (one 16-byte exchange) overlaps the GPU passes after it
         pending.append(fe.submit_shard_tensor(iq, plan["lo"], plan["own_lo"], plan["own_hi"], stream_len,
                                               head_cands=sharding.HEAD_CANDS))
         if len(pending) == DEPTH:
-            return collect_shard(pending.pop(0))
+            last_n[0] = collect_shard(pending.pop(0))
         return 0
 
     def ungated():
@@ -669,11 +669,12 @@ def main():
         dist.all_gather_object(out, o, group=host_group)
         return out
 
+    last_n = [0]
+
     def drain():
-        n = 0
         while pending:
-            n = fe.wait(pending.pop(0), fetch=False) if n_gpus == 1 else collect_shard(pending.pop(0))
-        return n
+            last_n[0] = fe.wait(pending.pop(0), fetch=False) if n_gpus == 1 else collect_shard(pending.pop(0))
+        return last_n[0]
 
     # barrier / max-over-ranks go over RCCL (backend "nccl") on the GPUs; if the communicator cannot be set up on
     # this node they fall back to the gloo side of the same process group rather than losing the run

@@ -10,7 +10,7 @@
 # plus the SQ instruction / wait counters for the headline workload and the full default bench line.
 # Counters are never collected together with sys / hip / hsa traces.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
@@ -45,8 +45,19 @@ for w in "${WL[@]}"; do
   rocprofv3 --kernel-trace --stats -d $W/kt1_$name -o kt1 -- $B $args --single-stream --steps 10 --warmup 3 --min-time 0.2 > $W/kt1_$name.log 2>&1
   DB=$(find $W/kt1_$name -name '*.db' | head -1)
   { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --no-extra --no-hostfed $args --single-stream --steps 10 --warmup 3 --min-time 0.2";
-    python $ROOT/tools/prof_summary.py "$DB" | grep -i "kernel \|adsb"; echo; echo "# the bench's own JSON line of this profiled run:";
+    python $ROOT/tools/prof_summary.py "$DB" | grep -i "kernel \|adsb\|copyBuffer"; echo; echo "# the bench's own JSON line of this profiled run:";
     grep '"metric"' $W/kt1_$name.log | tail -1; } > $OUT/${R}_${name}_kernel_trace_single_stream.txt 2>&1
+  # 1c. BLOCKING passes (--depth 1): what the profiler can time faithfully.  rocprofv3 turns SDMA off, so every device->host
+  #     record copy becomes a blit KERNEL (__amd_rocclr_copyBuffer, 0.28 ms for the headline's 15 MB) that, in the pipelined
+  #     runs above, executes beside the next pass's k_detect and slows it (profiles/r04_launch_hist_why_sc8.txt: a plain run
+  #     with HSA_ENABLE_SDMA=0 shows the same slow mode without any profiler).  With one pass in flight nothing overlaps:
+  #     this k_detect average is the one to hold against `roofline.isolated` of the unprofiled line
+  rocprofv3 --kernel-trace --stats -d $W/kt2_$name -o kt2 -- $B $args --depth 1 --steps 10 --warmup 3 --min-time 0.2 > $W/kt2_$name.log 2>&1
+  DB=$(find $W/kt2_$name -name '*.db' | head -1)
+  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --no-extra --no-hostfed $args --depth 1 --steps 10 --warmup 3 --min-time 0.2";
+    echo "# (one pass in flight: the record copy -- a blit kernel under the profiler, SDMA otherwise -- never runs beside k_detect)";
+    python $ROOT/tools/prof_summary.py "$DB" | grep -i "kernel \|adsb\|copyBuffer"; echo; echo "# the bench's own JSON line of this profiled run:";
+    grep '"metric"' $W/kt2_$name.log | tail -1; } > $OUT/${R}_${name}_kernel_trace_blocking.txt 2>&1
   # 2. HBM traffic counters, one pass each
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C --kernel-trace -f csv -d $W/pmc_${C}_$name -o p -- $B $args --steps 4 --warmup 1 --min-time 0 > $W/pmc_${C}_$name.log 2>&1

@@ -86,14 +86,12 @@ def _drive_blocks_vs_golden(g, sched, improved=False):
     assert np.float32(fr.prev_in0).view(np.uint32) == g.get(sched, "final_prev_in0_bits")
 
 
-@pytest.mark.parametrize("name", large_golden_names() + rate_golden_names())
-@pytest.mark.parametrize("sched", ["fixed2048", "random", "randombig"])
+@pytest.mark.parametrize("name,sched", [(n_, s_) for n_ in large_golden_names() + rate_golden_names()
+                                        for s_ in schedules_of(n_) if s_ != "single"])
 def test_dropin_blocks_match_large_reference_goldens(native, name, sched):
     """The drop-in blocks, work() call by work() call, against the reference under the deaf-state schedule (fixed 2048,
     framer.py:177-179) and a random 1000-9000 schedule over megasample streams; the rate goldens (R*: k_pass_small<0> for
     calls of up to four units, k_detect<1, 0> + k_tail_small beyond) also under chunks of 150-1500 symbols."""
-    if sched not in schedules_of(name):
-        pytest.skip("schedule not stored for this vector")
     _drive_blocks_vs_golden(Golden(name), sched)
 
 

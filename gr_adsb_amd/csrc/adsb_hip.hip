@@ -288,12 +288,13 @@ struct adsb_ctx {
   bool own_stream = false;
   int n_cu = 256;
   int bpc[ADSB_FMT_COUNT] = {4, 4, 4, 4, 4};  // resident k_detect workgroups per CU (occupancy query), per input format
-  // Unused dynamic LDS per k_detect workgroup = how many workgroups share a CU (28.3 KB static: five fit).  Measured per
-  // format on MI355X (tools/r3_variants.sh, 2^30 samples): five per CU for complex64, int16 (+1.4 % over four) and the
-  // 8-bit formats (int8 +8.3 %, uint8 +8.7 % over four; three: -24 %); FOUR for float |IQ|^2 (five: -2.5 %) -- 6 KB of
-  // padding lifts a workgroup over the 32 KB that five per CU allow.  (Earlier in round 3, with more vector
-  // instructions per sample, four was fastest for every narrow format: the choice follows the instruction mix.)
-  unsigned det_dyn_lds[ADSB_FMT_COUNT] = {0, 6144, 0, 0, 0};
+  // Unused dynamic LDS per k_detect workgroup = how many workgroups share a CU (28.3 KB static: five fit; 6 KB of padding
+  // would lift a workgroup over the 32 KB that five per CU allow).  Measured per format on MI355X (tools/r3_variants.sh,
+  // 2^30 samples): five per CU for every format since round 4 -- float |IQ|^2 ran best with four until the SGPR spills went
+  // (five: +1.3 % pipelined, 0.78 instead of 0.72 of its roofline isolated; profiles/r04_ab_workgroups_per_cu.txt); three:
+  // -24 % for the 8-bit formats.  Six would need 1.4 KB less LDS per workgroup: a 256-entry rise list worked off in two
+  // halves was built and measured -- six workgroups gave the 8-bit formats +5 %, the second code path took 4 % back.
+  unsigned det_dyn_lds[ADSB_FMT_COUNT] = {0, 0, 0, 0, 0};
   unsigned lds_beside[ADSB_FMT_COUNT] = {0, 0, 0, 0, 0};    // LDS a CU has left beside its resident k_detect workgroups
   // integer IQ component -> float32 multiplier per format (adsb_set_format_scale); unused for the float formats
   float scale[ADSB_FMT_COUNT] = {1.0f, 1.0f, 1.0f / 32768.0f, 1.0f / 128.0f, 1.0f / 255.0f};

@@ -128,9 +128,10 @@ def test_run_time_stride_other_formats(native, torch_mod, name):
 
 @pytest.mark.parametrize("name", bulk_golden_names())
 def test_bulk_reference_golden(native, torch_mod, name):
-    """tests/golden/B*.npz (round 4): 2^28 samples at 2 Msps, generated on the device by tests/lcg_stream.py (the same integer
-    hashing the build container ran in NumPy: identical bytes), against what the UNMODIFIED reference produced for them
-    in one work() call -- 32 k tags and PDUs.  This is the size at which a pass runs as eight resident rounds of short
+    """tests/golden/B*.npz (round 4): 2^28 samples at 2 / 8 / 20 Msps, generated on the device by tests/lcg_stream.py (the same
+    integer hashing the build container ran in NumPy: identical bytes), against what the UNMODIFIED reference produced for them
+    in one work() call -- 32 k / 43 k / 8 k tags and PDUs (8 and 20 Msps: bursts longer than the LDS window, bits taken tile by
+    tile from the pending list).  This is the size at which a pass runs as eight resident rounds of short
     chunks (adsb_plan.h) and the usual-tile instance (EASY) carries all but the first and last tiles: the bulk device path
     itself pinned by the reference, through the int8, complex64 and |IQ|^2 entry points."""
     import lcg_stream

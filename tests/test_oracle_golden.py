@@ -96,7 +96,7 @@ def test_c_oracle_matches_bulk_reference_golden_on_a_prefix(name):
     r = C.canonical(g.x, g.sps, np.float32(g.thr))
     offs = g.get("single", "tag_offsets")
     k = int(np.searchsorted(offs, n - 8 * g.sps + 1))            # tags the prefix call can see: centre < n - (H - 1)
-    assert k > 500 and np.array_equal(r["offset"], offs[:k])
+    assert k > 200 and np.array_equal(r["offset"], offs[:k])
     assert np.array_equal(snr_bits(r["peak"], r["median"]), g.get("single", "tag_snr_bits")[:k])
     dem = (r["flags"] & 1) != 0
     kp = int(dem.sum())

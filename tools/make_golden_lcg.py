@@ -5,15 +5,15 @@
                         library's maximum, 100 Msps -- served by the run-time-stride kernels k_detect<fmt, 0> /
                         k_pass_small<0>.  2^20 - 2^22 samples each, single call + fixed 2048 (deaf-state) + two random
                         chunk schedules.
-  tests/golden/B*.npz   one BULK vector: 2^28 samples at 2 Msps (134 s of signal, ~32 k bursts): the size at which the
+  tests/golden/B*.npz   BULK vectors: 2^28 samples at 2 / 8 / 20 Msps (~32 k / 44 k / 8 k bursts): the size at which the
                         library cuts a pass into eight rounds of short chunks (adsb_plan.h plan_chunks) and the usual-tile
-                        instance carries everything -- the reference's own tags and PDUs for it, single call.
+                        instance carries everything -- the reference's own tags and PDUs for them, single call.
 
 The input of every vector is tests/lcg_stream.py (integer hashing of the sample index; NumPy here, torch on the GPU box:
 identical bytes); the .npz holds the generator's parameters and what the unmodified framer.py / demod.py produced for
 |IQ|^2 of those bytes (component = f32(int8) * scale, one rounded multiply; re*re + im*im).  No reference source is stored.
 
-  python tools/make_golden_lcg.py [rates] [bulk]
+  python tools/make_golden_lcg.py [rates] [bulk [B8msps_bulk ...]]
 """
 import os
 import sys
@@ -44,7 +44,13 @@ RATES = [
     ("R40msps", 40, 1 << 21, 9000, 406, 0.01),
     ("R100msps", 100, 1 << 22, 16000, 407, 0.005),   # the library's maximum (adsb_create): preamble span 800 samples
 ]
-BULK = ("B2msps_bulk", 2, 1 << 28, 8192, 501, 0.005)
+BULKS = [
+    ("B2msps_bulk", 2, 1 << 28, 8192, 501, 0.005),
+    # round 4, second batch: the instances with the preamble taps 4 and 10 samples apart at bulk size -- bursts longer than
+    # the LDS window (960 / 2400 samples), whose bits are taken tile by tile from the wavefront's pending list
+    ("B8msps_bulk", 8, 1 << 28, 6144, 502, 0.005),
+    ("B20msps_bulk", 20, 1 << 28, 32768, 503, 0.01),
+]
 
 
 def mag2_of(iq8):
@@ -75,8 +81,14 @@ def rates():
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **data)
 
 
-def bulk():
-    name, sps, n, gap, seed, thr = BULK
+def bulk(only=None):
+    for spec in BULKS:
+        if only and spec[0] not in only:
+            continue
+        bulk_one(*spec)
+
+
+def bulk_one(name, sps, n, gap, seed, thr):
     p = L.params(n, sps, seed, gap)
     t0 = time.time()
     x = mag2_of(L.stream(p))
@@ -95,4 +107,4 @@ if __name__ == "__main__":
     if "rates" in what:
         rates()
     if "bulk" in what:
-        bulk()
+        bulk([w for w in what if w.startswith("B")])

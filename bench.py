@@ -171,11 +171,6 @@ def run_single_gpu_config(fe, fmt, iq, n, steps, warmup, min_time, depth):
     """Pipelined canonical passes over a resident buffer; returns (median ms/step, times, stats, bursts, iso_ms)."""
     for _ in range(2):
         fe.ctx.process_format_device(fmt, iq.data_ptr(), n, 0, fetch=False)
-    fe.ctx.reset_stats()
-    for _ in range(4):
-        fe.ctx.process_format_device(fmt, iq.data_ptr(), n, 0, fetch=False)
-    s0 = fe.stats()
-    iso_ms = s0["detect_ms"] / max(1, s0["detect_launches"])
     import torch
     pending = []
 
@@ -195,7 +190,19 @@ def run_single_gpu_config(fe, fmt, iq, n, steps, warmup, min_time, depth):
     drain()
     fe.ctx.reset_stats()
     times, nb = timed_repeats(step, drain, torch.cuda.synchronize, lambda t: t, steps, min_time)
-    return float(np.median(times)) / steps * 1e3, times, fe.stats(), nb, iso_ms
+    st = fe.stats()
+    return float(np.median(times)) / steps * 1e3, times, st, nb, isolated_kernel_ms(fe, fmt, iq, n)
+
+
+def isolated_kernel_ms(fe, fmt, iq, n, launches=8):
+    """k_detect alone: blocking passes, nothing else on the GPU, HIP events around the kernel.  Measured AFTER the timed
+    region, on a GPU whose clocks are up (a fresh box ramps its shader clock by ~10 % over the first dozens of launches:
+    profiles/r04_cu_probe.txt; measured in front of the timed region this figure was 2-5 % pessimistic)."""
+    fe.ctx.reset_stats()
+    for _ in range(launches):
+        fe.ctx.process_format_device(fmt, iq.data_ptr(), n, 0, fetch=False)
+    s0 = fe.stats()
+    return s0["detect_ms"] / max(1, s0["detect_launches"])
 
 
 def sharded_on_one_gpu(fe, iq, n, sps, shards, depth):
@@ -707,16 +714,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=sync_group())
         return float(tmax.item())
 
-    # the same kernel timed without a neighbour, BEFORE the timed region (it also brings a fresh box's clocks up)
-    iso_ms = None
+    # a few blocking passes in front of everything (they also bring a fresh box's clocks up)
     if n_gpus == 1:
-        for _ in range(3):
+        for _ in range(6):
             fe.ctx.process_format_device(fmt, iq.data_ptr(), n_own, 0, fetch=False)
-        fe.ctx.reset_stats()
-        for _ in range(5):
-            fe.ctx.process_format_device(fmt, iq.data_ptr(), n_own, 0, fetch=False)
-        st_iso = fe.stats()
-        iso_ms = st_iso["detect_ms"] / max(1, st_iso["detect_launches"])
 
     for _ in range(args.warmup):
         step()
@@ -731,6 +732,8 @@ def main():
     times, n_bursts = timed_repeats(step, drain, sync_all, reduce_and_keep, args.steps, args.min_time)
     elapsed = float(np.median(times))
     st = fe.stats()
+    # the same kernel timed without a neighbour, AFTER the timed region
+    iso_ms = isolated_kernel_ms(fe, fmt, iq, n_own) if n_gpus == 1 else None
 
     # every rank reports; rank 0 prints (N>1: the record says what each rank saw)
     per_rank = None

@@ -360,11 +360,17 @@ int ensure(adsb_ctx* c, DevBuf& b, size_t bytes) {
 constexpr int kMpolDefault = 0, kMpolPreferred = 1;
 hipError_t host_alloc_near(adsb_ctx* c, void** p, size_t bytes) {
   if (!c || c->numa_node < 0 || c->numa_node >= 1024) return hipHostMalloc(p, bytes, hipHostMallocDefault);
-  unsigned long mask[16] = {0};
+  unsigned long mask[16] = {0}, old_mask[16] = {0};
   mask[c->numa_node / (8 * sizeof(unsigned long))] |= 1ul << (c->numa_node % (8 * sizeof(unsigned long)));
+  // the caller's own policy is put back afterwards (whatever it was)
+  int old_mode = kMpolDefault;
+  const bool have_old = syscall(SYS_get_mempolicy, &old_mode, old_mask, sizeof(old_mask) * 8, nullptr, 0) == 0;
   const long rc = syscall(SYS_set_mempolicy, kMpolPreferred, mask, sizeof(mask) * 8);
   hipError_t e = hipHostMalloc(p, bytes, rc == 0 ? hipHostMallocNumaUser : hipHostMallocDefault);
-  if (rc == 0) (void)syscall(SYS_set_mempolicy, kMpolDefault, nullptr, 0);
+  if (rc == 0) {
+    if (!have_old || old_mode == kMpolDefault || syscall(SYS_set_mempolicy, old_mode, old_mask, sizeof(old_mask) * 8) != 0)
+      (void)syscall(SYS_set_mempolicy, kMpolDefault, nullptr, 0);
+  }
   if (e != hipSuccess && rc == 0) { (void)hipGetLastError(); e = hipHostMalloc(p, bytes, hipHostMallocDefault); }
   return e;
 }
@@ -552,7 +558,7 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   }
   hipLaunchKernelGGL(k_count, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted,
                      (const Summary*)&misc->sum, fmask, fwant, pl.head_n, (int*)s.d_seg.p);
-  // k_compact's last workgroup stores the summary straight into s.h_sum (pinned host memory, device-visible): visible to the
+  // k_compact's workgroup 0 stores the summary straight into s.h_sum (pinned host memory, device-visible): visible to the
   // host once the `done` event below has completed
   hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted, (const Rec*)a.recs, (const unsigned*)sorted_src,
                      &misc->sum, (const int*)s.d_seg.p, fmask, fwant, pl.head_n, (Rec*)(s.direct ? s.h_out : s.d_out.p), (int)s.tot,

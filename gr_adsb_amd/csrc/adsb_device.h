@@ -26,8 +26,8 @@
 // (marks a wavefront-uniform value so it lives in a scalar register), `adsb_readlane(int, lane)` and
 // `adsb_bitrep32(u32) -> u64` (every bit doubled: s_bitreplicate_b64_b32), `adsb_opaque(int)` (returns its argument
 // through an empty asm statement, so that nothing derived from it is treated as loop invariant) and
-// `adsb_ld_stream<Q>(const char*)` (one Q-sized load of streamed, single-use data), `adsb_sdot4(int, int)` (the sum of the
-// four products of the signed bytes of two words: v_dot4_i32_i8), `adsb_cold(const DetectArgs&)` (a pointer
+// `adsb_ld_stream<Q>(const char*)` (one Q-sized load of streamed, single-use data), `adsb_sdot4(int a, int b, int c)` (c + the sum of the
+// four products of the signed bytes of a and b: v_dot4c_i32_i8), `adsb_cold(const DetectArgs&)` (a pointer
 // to the same argument block as it lies in the kernel's argument memory, opaque to the optimiser: rarely needed fields are
 // loaded where they are used instead of occupying scalar registers across the tile loop), and the macro ADSB_LDS (the
 // address-space qualifier of workgroup-local memory, empty for the emulator): the
@@ -753,18 +753,23 @@ __device__ __forceinline__ void body_convert(const float4& q, float scale, float
     m[2] = mag2_iq16(__builtin_bit_cast(unsigned, q.z), scale);
     m[3] = mag2_iq16(__builtin_bit_cast(unsigned, q.w), scale);
   } else if constexpr (MODE == kModeSc8Pow2) {
-    // power-of-two scale: i*i + q*q as an integer (v_dot4_i32_i8 on the packed bytes, the other sample's bytes masked out of
-    // one operand), one conversion, one multiply by scale^2 -- 3.5 instead of 4.5 vector instructions per sample, every
-    // step exact (integers below 2^15, then a power of two)
+    // power-of-two scale: i*i + q*q as an integer (v_dot4c_i32_i8 on the packed bytes) -- 3 instead of 4.5 vector
+    // instructions per sample, every step exact (integers below 2^16, then a power of two)
     const unsigned u[4] = {__builtin_bit_cast(unsigned, q.x), __builtin_bit_cast(unsigned, q.y),
                            __builtin_bit_cast(unsigned, q.z), __builtin_bit_cast(unsigned, q.w)};
     const float s2 = __fmul_rn(scale, scale);
+    // The first sample of a word: the other sample's bytes masked out of one operand.  The dot product ACCUMULATES (v_dot4c_i32_i8 adds onto its destination): started from the bit pattern of 2^23 the sum IS
+    // the float 2^23 + (i*i + q*q) (sum < 2^16), and one fused multiply-add per sample -- (2^23 + m) * s2 - 2^23 * s2, exact
+    // for a power-of-two s2 -- replaces the conversion and the multiply.  The second sample of a word: all four byte
+    // products onto (2^23 - m0), i.e. 2 * bits(2^23) minus the first result, instead of a second masked operand.
+    constexpr unsigned kTwo23 = 0x4B000000u;
+    const float c23 = -__fmul_rn(8388608.0f, s2);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int s0 = adsb_sdot4((int)u[j], (int)(u[j] & 0x0000FFFFu));
-      const int s1 = adsb_sdot4((int)u[j], (int)(u[j] & 0xFFFF0000u));
-      m[2 * j] = __fmul_rn((float)s0, s2);
-      m[2 * j + 1] = __fmul_rn((float)s1, s2);
+      const unsigned a0 = (unsigned)adsb_sdot4((int)u[j], (int)(u[j] & 0x0000FFFFu), (int)kTwo23);
+      const unsigned a1 = (unsigned)adsb_sdot4((int)u[j], (int)u[j], (int)(2u * kTwo23 - a0));
+      m[2 * j] = __builtin_fmaf(__builtin_bit_cast(float, a0), s2, c23);
+      m[2 * j + 1] = __builtin_fmaf(__builtin_bit_cast(float, a1), s2, c23);
     }
   } else {
     const unsigned u[4] = {__builtin_bit_cast(unsigned, q.x), __builtin_bit_cast(unsigned, q.y),

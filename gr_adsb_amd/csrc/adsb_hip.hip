@@ -45,8 +45,8 @@ __device__ __forceinline__ int adsb_opaque(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
-// sum of the four products of the signed bytes of a and b (v_dot4_i32_i8)
-__device__ __forceinline__ int adsb_sdot4(int a, int b) { return __builtin_amdgcn_sdot4(a, b, 0, false); }
+// c + the sum of the four products of the signed bytes of a and b (v_dot4c_i32_i8)
+__device__ __forceinline__ int adsb_sdot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
 // streamed single-use data: non-temporal load (every sample is fetched exactly once)
 template <class Q>
 __device__ __forceinline__ Q adsb_ld_stream(const char* p) {

@@ -187,3 +187,19 @@ def grc_instantiate(descriptor, **overrides):
         for cb in descriptor["templates"].get("callbacks", []):
             eval("blk." + sub(cb, vals), dict(ns, blk=blk))
     return blk, callbacks
+
+
+def every_byte_pair_stream(scale, slot=256):
+    """int8 IQ, 2 Msps: slot k holds 100 samples of byte pair W_k (a constant noise window), one zero, then a preamble
+    whose four high chips are byte pair V_k = k (i = low byte, q = high byte) -- every pair once as a record's peak and
+    once as its median.  Returns (iq8, threshold): the threshold lies below the smallest non-zero |IQ|^2."""
+    k = np.arange(65536, dtype=np.int64)
+    pair = np.zeros((65536 * slot,), dtype=np.uint16)
+    w = ((k * 40503 + 12345) & 0xFFFF).astype(np.uint16)
+    base = k * slot
+    for j in range(20, 120):
+        pair[base + j] = w
+    for c in (0, 2, 7, 9):
+        pair[base + 121 + c] = k.astype(np.uint16)
+    s2 = np.float32(scale) * np.float32(scale)
+    return pair.view(np.int8), np.float32(0.75) * s2

@@ -258,10 +258,10 @@ template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return 
 template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
-inline int adsb_sdot4(int a, int b) {
-  int r = 0;
-  for (int k = 0; k < 4; ++k) r += (int)(signed char)((unsigned)a >> (8 * k)) * (int)(signed char)((unsigned)b >> (8 * k));
-  return r;
+inline int adsb_sdot4(int a, int b, int c) {
+  unsigned r = (unsigned)c;
+  for (int k = 0; k < 4; ++k) r += (unsigned)((int)(signed char)((unsigned)a >> (8 * k)) * (int)(signed char)((unsigned)b >> (8 * k)));
+  return (int)r;
 }
 inline void __threadfence() {}
 inline void __threadfence_system() {}

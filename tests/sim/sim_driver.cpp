@@ -160,6 +160,18 @@ void sim_geometry(int* tile, int* fwd, int* back) { *tile = kWTile; *fwd = kFwd;
 void sim_set_confidence_out(float* p) { g_conf_out = p; }
 void sim_set_tail_mode(int m) { g_tail_mode = m; }
 
+// k_detect's own conversion of one 16-byte load (body_convert) for the 8-bit formats: words[4*k .. 4*k+4) -> out[8*k .. 8*k+8).
+// mode 3 int8, 4 offset-binary uint8, 5 the power-of-two-scale int8 instance (v_dot4c_i32_i8, see adsb_device.h).
+void sim_convert8(int mode, const unsigned* words, long long nwords, float scale, float* out) {
+  for (long long k = 0; k + 4 <= nwords; k += 4) {
+    float4 q;
+    memcpy(&q, words + k, 16);
+    if (mode == 3) body_convert<3>(q, scale, out + 2 * k);
+    else if (mode == 4) body_convert<4>(q, scale, out + 2 * k);
+    else body_convert<kModeSc8Pow2>(q, scale, out + 2 * k);
+  }
+}
+
 // --- the library's three call shapes, through the same adsb_plan.h the library uses ------------------
 int sim_canonical(int mode, const float* data, long long n, long long abs_offset, float thr, int sps, int grid_max,
                   int rec_cap, float scale, unsigned long long* out, int out_cap, SimOut* so) {

@@ -50,6 +50,15 @@ def kernel_geometry():
     return t.value, f.value, b.value
 
 
+def convert8(mode, iq8, scale):
+    """body_convert<mode> (k_detect's in-register conversion) of interleaved 8-bit IQ -> float32 |IQ|^2; len(iq8) % 16 == 0."""
+    raw = np.ascontiguousarray(iq8).view(np.uint32)
+    out = np.empty(2 * len(raw), dtype=np.float32)
+    lib().sim_convert8(ctypes.c_int(mode), raw.ctypes.data_as(ctypes.c_void_p), ctypes.c_longlong(len(raw)),
+                       ctypes.c_float(scale), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
 def sim_run(mode, data, sps, thr, in0_base, scan_lo, scan_hi, fall_hi, dem_hi, origin=0, prev_in0=0.0,
             end_is_call_end=1, prev_eob_stream=None, gate=True, grid_max=6, rec_cap=0, scale=1.0):
     """mode 0: complex64[n]; 1: float32 |IQ|^2 [n]; 2: int16 / 3: int8 / 4: uint8 interleaved IQ [2n]."""

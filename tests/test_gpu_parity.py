@@ -6,7 +6,7 @@ import warnings
 import numpy as np
 import pytest
 
-from helpers import (SCHEDULES, Golden, assert_recs_equal, assert_recs_match_golden, bulk_golden_names, golden_names,
+from helpers import (SCHEDULES, Golden, every_byte_pair_stream, assert_recs_equal, assert_recs_match_golden, bulk_golden_names, golden_names,
                      large_golden_names, pathological_names, rate_golden_names, schedules_of, snr_bits, unpack)
 
 pytestmark = pytest.mark.gpu
@@ -159,6 +159,24 @@ def test_bulk_reference_golden(native, torch_mod, name):
     del v, prod, iq
     torch.cuda.synchronize()
     assert_recs_match_golden(ctx.process_mag2_device(x.data_ptr(), n), g)
+    ctx.close()
+
+
+@pytest.mark.parametrize("scale", [1.0 / 128.0, 4.0, 2.0 ** -20, 3.0 / 128.0])
+def test_int8_every_byte_pair_as_peak_and_as_median(native, scale):
+    """int8 IQ, all 65536 (i, q) byte pairs: each once as the four high chips of a preamble (the record's peak) and once as
+    a constant 100-sample noise window (its median), 16.7 M samples, against the C oracle on the oracle's conversion
+    f32(i8) * scale squared and summed.  Power-of-two scales run k_detect<5, .>, whose |IQ|^2 is the v_dot4c_i32_i8 sum
+    accumulated onto the bit pattern of 2^23 and one fused multiply-add (adsb_device.h body_convert); 3/128 the generic
+    chain."""
+    from oracle import adsb_oracle as O
+    from oracle import c_oracle as C
+    iq8, thr = every_byte_pair_stream(scale)
+    want = C.canonical(O.mag2_iq8(iq8, scale), 2, thr)
+    assert len(want) >= 65000
+    ctx = native.Context(2e6, float(thr))
+    ctx.set_format_scale(native.FMT_SC8, float(scale))
+    assert_recs_equal(ctx.process_format(native.FMT_SC8, iq8), want, "every byte pair, scale %g" % scale)
     ctx.close()
 
 

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import simlib
-from helpers import Golden, assert_recs_equal, assert_recs_match_golden, golden_names, rate_golden_names, snr_bits, unpack
+from helpers import every_byte_pair_stream, Golden, assert_recs_equal, assert_recs_match_golden, golden_names, rate_golden_names, snr_bits, unpack
 from gr_adsb_amd import modulator as M
 from oracle import adsb_oracle as O
 from oracle import c_oracle as C
@@ -474,3 +474,31 @@ def test_sample_rates_without_their_own_instance(sps):
         got, so = simlib.sim_canonical(1, x, sps * 1e6, 0.01, grid_max=gm)
         assert so.overflow == 0
         assert_recs_equal(got, want, "sps %d grid_max %d" % (sps, gm))
+
+
+@pytest.mark.parametrize("scale", [1.0 / 128.0, 4.0, 2.0 ** -20, 2.0 ** 30])
+def test_int8_power_of_two_scale_conversion_every_byte_pair(scale):
+    """body_convert of the power-of-two instance (k_detect<5, .>: the dot product accumulated onto the bit pattern of 2^23,
+    one fused multiply-add) == the generic int8 chain == the oracle's f32(i8)*scale squared and summed, for all 65536 byte
+    pairs in both sample positions of a word."""
+    k = np.arange(65536, dtype=np.uint32)
+    words = np.concatenate([k | (np.roll(k, 7919) << 16), (k << 16) | np.roll(k, 104729 % 65536)]).astype(np.uint32)
+    iq8 = words.view(np.int8)
+    want = O.mag2_iq8(iq8, scale)
+    for mode in (3, 5):
+        got = simlib.convert8(mode, iq8, scale)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), mode
+    u8 = words.view(np.uint8)
+    assert np.array_equal(simlib.convert8(4, u8, scale).view(np.uint32), O.mag2_iq8(u8, scale, True).view(np.uint32))
+
+
+def test_int8_power_of_two_scale_every_byte_pair_through_the_kernels():
+    """a slice of every_byte_pair_stream (4096 pairs as peaks, 4096 others as medians) through the emulated kernels."""
+    iq8, thr = every_byte_pair_stream(1.0 / 128.0)
+    lo, hi = 2 * 256 * 30000, 2 * 256 * 34096
+    seg = np.ascontiguousarray(iq8[lo:hi])
+    want = C.canonical(O.mag2_iq8(seg, 1.0 / 128.0), 2, thr)
+    assert len(want) >= 4000
+    recs, so = simlib.sim_canonical(3, seg, 2e6, float(thr), scale=1.0 / 128.0)
+    assert so.overflow == 0
+    assert_recs_equal(recs, want, "every byte pair")

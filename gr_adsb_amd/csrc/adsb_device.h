@@ -1143,25 +1143,50 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
     // from `clamp` too; its floats are then written by the scalar loop, zeros past the end.
     const char* const clamp = reinterpret_cast<const char*>(cold()->data) + (((cold()->n - kWTile) * (long long)BPS) & ~15ll);
     const char* nb = reinterpret_cast<const char*>(cold()->data) + (c0 + kFwd) * (long long)BPS;      // this tile's body
-    Body<MODE> body;
+    // Prefetch depth D (tiles in flight per wavefront); the loop is unrolled D times so that each body is a fixed set of
+    // registers and the compiler's s_waitcnt in front of a commit counts exactly the younger bodies' loads (a rotating set
+    // meets a wait for everything at the loop head: round 3's attempt).  Measured with exact waits (round 4,
+    // profiles/r04_ab_prefetch_depth.txt): two tiles ahead +2.2 % for int8 IQ with the dot-product conversion (the format
+    // with the least arithmetic per byte), +0.8 % int16, 0 for uint8 / |IQ|^2 floats / complex64, three no better than
+    // two -- the narrow formats are NOT short of bytes in flight; kept where it pays for its 50 % more code.
+    constexpr int D = (MODE == kModeSc8Pow2) ? 2 : 1;
+    Body<MODE> body[D];
     if (ntile > 0) {
-      body_issue(body, it_rag > 0 ? nb : clamp, lane);
+      body_issue(body[0], it_rag > 0 ? nb : clamp, lane);
+#pragma unroll
+      for (int d = 1; d < D; ++d) {                            // tile d: loadable iff d - 1 < it_re
+        nb += (long long)kWTile * BPS;
+        body_issue(body[d], d - 1 < it_re ? nb : clamp, lane);
+      }
       head_fill(lane);
     }
-    for (int it = 0; it < ntile; ++it) {
+    // nb: the body of tile it + D - 1 when step `it` starts
+    auto step = [&](Body<MODE>& b, const int it, const bool real) {
       // The lane number through an opaque copy, renewed every tile: otherwise lane-derived addresses are hoisted out of
       // this loop as loop-invariant registers, which the register budget of five wavefronts per SIMD cannot hold.
       const int lane = adsb_opaque(lane_outer);
       const long long t0 = c0 + (long long)it * kWTile;        // (only the rare paths use it)
-      nb += (long long)kWTile * BPS;                           // now: the NEXT tile's body
-      const int mx = body_commit<MODE, true>(body, s_x + kFwd, a.scale, lane, it < it_re ? nb : clamp);
-      bool active = !thr_pos || __ballot(mx >= thr_bits) != 0ull;
-      if (it >= it_rag) {
-        adsb_wave_sync();                                      // every lane's commit stores lie in front of the rewrite below
-        for (int i = lane; i < kWTile; i += 64) s_x[kFwd + i] = xg<MODE>(cold()->data, cold()->n, t0 + kFwd + i, a.scale);
-        active = true;
+      nb += (long long)kWTile * BPS;                           // now: the body of tile it + D, which these registers hold next
+      const int mx = body_commit<MODE, true>(b, s_x + kFwd, a.scale, lane, it + D - 1 < it_re ? nb : clamp);
+      if (real) {
+        bool active = !thr_pos || __ballot(mx >= thr_bits) != 0ull;
+        if (it >= it_rag) {
+          adsb_wave_sync();                                    // every lane's commit stores lie in front of the rewrite below
+          for (int i = lane; i < kWTile; i += 64) s_x[kFwd + i] = xg<MODE>(cold()->data, cold()->n, t0 + kFwd + i, a.scale);
+          active = true;
+        }
+        process_tile(it, t0, active, lane);
       }
-      process_tile(it, t0, active, lane);
+    };
+    // A chunk with a number of tiles that is not a multiple of D ends inside the unrolled body: the steps past its end still
+    // COMMIT (floats nobody reads, a reload from `clamp`) and skip the tile's work.  Leaving the loop there instead gives
+    // the compiler a second path to the loop head on which the OTHER body's loads are the younger ones, and it then waits
+    // for all loads in front of every commit (measured: that is what made the first attempt at two tiles ahead, in round
+    // 3, worthless).
+    for (int it = 0; it < ntile; it += D) {
+      step(body[0], it, true);
+#pragma unroll
+      for (int d = 1; d < D; ++d) step(body[d], it + d, it + d < ntile);
     }
   } else {
     // -- inputs shorter than one tile (a GNU Radio work() call of a few hundred samples): scalar reads only

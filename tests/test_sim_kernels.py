@@ -502,3 +502,22 @@ def test_int8_power_of_two_scale_every_byte_pair_through_the_kernels():
     recs, so = simlib.sim_canonical(3, seg, 2e6, float(thr), scale=1.0 / 128.0)
     assert so.overflow == 0
     assert_recs_equal(recs, want, "every byte pair")
+
+
+@pytest.mark.parametrize("fs,bps", [(2e6, 5000), (8e6, 6000), (12e6, 4000)])
+def test_two_tiles_ahead_chunks_of_every_length(fs, bps):
+    """The int8 power-of-two-scale instance keeps TWO tile bodies in flight (tile loop unrolled twice, adsb_device.h): chunks of
+    odd and even numbers of tiles, streams that end in the first or the second half of the unrolled body, ragged last tiles,
+    one resident round and several -- against the C oracle."""
+    T, F, B = simlib.kernel_geometry()
+    sps = int(fs // 1e6)
+    scale = 4.0 / 128.0
+    iq = M.synth_iq(9 * T + 700, fs, bps, seed=sps)
+    q8 = M.quantize_iq8(iq, full_scale=4.0 * 127.0 / 128.0)
+    for n in (T - 1, T, T + 1, 2 * T + F, 3 * T + F + 5, 4 * T + 17, 5 * T + F, 7 * T + 300, 9 * T + 700):
+        seg = np.ascontiguousarray(q8[:2 * n])
+        want = C.canonical(O.mag2_iq8(seg, scale), sps, np.float32(0.01))
+        for grid_max in (1, 2, 40):
+            got, so = simlib.sim_canonical(3, seg, fs, 0.01, grid_max=grid_max, scale=scale)
+            assert so.overflow == 0
+            assert_recs_equal(got, want, "n %d grid %d" % (n, grid_max))

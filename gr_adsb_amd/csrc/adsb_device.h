@@ -1442,11 +1442,22 @@ __global__ void __launch_bounds__(kThreads) k_order(DetectArgs a, int nblk, unsi
     struct alignas(16) I4 { int x, y, z, w; };
     const int nfront = bid * kOrderLists;                       // a multiple of 4: whole 16-byte groups only
     const I4* c4 = reinterpret_cast<const I4*>(a.blk_count);
-    for (int i = tid; i < nfront / 4; i += kThreads) {
-      const I4 v = c4[i];
-      before += (v.x < rec_cap ? v.x : rec_cap) + (v.y < rec_cap ? v.y : rec_cap) + (v.z < rec_cap ? v.z : rec_cap) +
-                (v.w < rec_cap ? v.w : rec_cap);
+    auto clipped = [&](const I4& v) {
+      return (v.x < rec_cap ? v.x : rec_cap) + (v.y < rec_cap ? v.y : rec_cap) + (v.z < rec_cap ? v.z : rec_cap) +
+             (v.w < rec_cap ? v.w : rec_cap);
+    };
+    // (eight loads in flight per thread: the last workgroup of a headline pass has forty groups per thread to add, and one
+    // L2 round trip each made this loop the longest part of the kernel)
+    const int n4 = nfront / 4;
+    int i = tid;
+    for (; i + 7 * kThreads < n4; i += 8 * kThreads) {
+      I4 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = c4[i + q * kThreads];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) before += clipped(v[q]);
     }
+    for (; i < n4; i += kThreads) before += clipped(c4[i]);
   }
   int front = 0, total = 0;
   (void)block_excl_scan(before, &front);                        // (barriers inside) front = sum over the workgroup
@@ -1454,12 +1465,13 @@ __global__ void __launch_bounds__(kThreads) k_order(DetectArgs a, int nblk, unsi
   // 3. words to their final places
   {
     const long long src = (long long)b * rec_cap;
-    for (int j = 0; j < cnt; j += 4) {
-      unsigned long long w[4];
+    constexpr int kAtOnce = 8;                                  // loads in flight per thread (a list of the headline pass: ~12 words)
+    for (int j = 0; j < cnt; j += kAtOnce) {
+      unsigned long long w[kAtOnce];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) w[q] = a.cands[src + (j + q < cnt ? j + q : j)];
+      for (int q = 0; q < kAtOnce; ++q) w[q] = a.cands[src + (j + q < cnt ? j + q : j)];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < kAtOnce; ++q)
         if (j + q < cnt) {
           sorted[run + j + q] = w[q];
           sorted_src[run + j + q] = (unsigned)(src + j + q);   // where its 32-byte record lies: read once, by k_compact

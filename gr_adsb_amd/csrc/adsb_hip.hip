@@ -549,13 +549,10 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   unsigned* sorted_src = (unsigned*)s.d_sorted_src.p;
   ADSB_BY_MODE(pl.mode, launch_order, ts, (s.nlists + kOrderLists - 1) / kOrderLists, order_pad, a, s.nlists, sorted, sorted_src,
                &misc->sum, &misc->acc);
-#ifndef ADSB_TAIL_GRID
-#define ADSB_TAIL_GRID 2048
-#endif
   // k_resolve / k_count / k_compact work in segments of 256 list words; a workgroup past the last segment returns at once.
   // 2048 workgroups (eight per CU) give every segment of a headline pass (≈1900) its own workgroup: one round instead of
   // four (512 workgroups: k_compact 22 us, k_resolve 11, k_count 5 for 477 k centres)
-  const int ag = ADSB_TAIL_GRID;
+  const int ag = 2048;
   unsigned fmask = 0u, fwant = 0u;
   if (pl.gate) {
     hipLaunchKernelGGL(k_resolve, dim3(ag), dim3(kThreads), 0, ts, sorted, (const Summary*)&misc->sum,

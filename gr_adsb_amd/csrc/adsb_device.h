@@ -647,10 +647,52 @@ __device__ __forceinline__ void burst_from_window(WinArgs<CP> a, const float* s_
   rec_store_bits(out, ma, mb, flags, lane);
 }
 
+// A wavefront's output stage.  Records and list words are not stored to global memory where they are made (lane 0, 16 + 16 + 8
+// bytes per burst, three store instructions at three different moments): they are collected in LDS and written kStage at a
+// time -- 512 + 128 contiguous bytes, one store instruction each, whole 128-byte lines -- or at the end of the chunk (the
+// usual list of a bulk pass, ~12 entries: once).  Why: HBM pays for every scattered partial-line write with a bus
+// turn-around in the middle of the read stream, and this kernel is HBM-bound: with the per-burst stores the complex64
+// headline ran 2.5-8 % slower than with none at all, by an amount that depended on where the pass's output buffers happened
+// to lie (profiles/r04_ab_output_stage.txt).
+constexpr int kStage = 16;
+struct alignas(16) StageBuf { Rec rec[kStage]; unsigned long long cand[kStage]; };
+struct Stage {
+  StageBuf* buf;               // LDS: slots [base, base + kStage) of this unit's list
+  Rec* recs;                   // the unit's list in global memory (a.recs + unit * rec_cap)
+  unsigned long long* cands;
+  int base;                    // wave-uniform: first slot still in the stage
+};
+// everything in front of slot `upto` (<= base + kStage) goes to global memory
+__device__ __forceinline__ void stage_flush(Stage& st, int upto, int lane) {
+  const int cnt = upto - st.base;                            // wave-uniform
+  if (cnt > 0) {
+    adsb_wave_sync();                                        // lane 0's stage writes lie in front of the reads below
+    if (lane < 2 * cnt) {
+      const RecHalf v = reinterpret_cast<const RecHalf*>(st.buf->rec)[lane];
+      reinterpret_cast<RecHalf*>(st.recs + st.base)[lane] = v;
+    }
+    if (lane < cnt) st.cands[st.base + lane] = st.buf->cand[lane];
+    adsb_wave_sync();                                        // ... and these reads in front of the stage's next use
+    st.base = upto;
+  }
+}
+
+// second half of a record that is still in the stage (the pointer is typed as LDS on purpose: a store through a generic
+// pointer next to the global-memory one of the other branch is merged with it into ONE flat store by the compiler)
+__device__ __forceinline__ void stage_store_bits(const Stage& st, int slot, unsigned long long ma, unsigned long long mb,
+                                                 unsigned flags, int lane) {
+  if (lane == 0) {
+    ADSB_LDS Rec* o = (ADSB_LDS Rec*)(st.buf->rec + (slot - st.base));
+    o->w[2] = __builtin_bswap64(__brevll(ma));
+    o->w[3] = (__builtin_bswap64(__brevll(mb)) & 0xFFFFFFFFFFFFull) | ((unsigned long long)flags << 48);
+  }
+}
+
 // Once per tile, after its body is in the window: every pending burst takes the bit pairs that have arrived; a burst
 // whose last pair is in is finished (second half of its record stored) and leaves the list.  t_next = false on the
 // tile the entries were made (nothing to do yet); the list is compacted in place, order kept.
-__device__ __forceinline__ void pend_step(PendList* pend, int* n_pend, const float* s_x, Rec* my_recs, int sps, int half, int lane) {
+template <bool STAGED>
+__device__ __forceinline__ void pend_step(PendList* pend, int* n_pend, const float* s_x, const Stage& st, int sps, int half, int lane) {
   int keep = 0;
   for (int i = 0; i < *n_pend; ++i) {                        // wave-uniform
     PendEntry e = pend->e[i];
@@ -660,7 +702,9 @@ __device__ __forceinline__ void pend_step(PendList* pend, int* n_pend, const flo
     e.ma |= ma; e.mb |= mb;
     adsb_wave_sync();                                        // every lane has read entry i before lane 0 rewrites the list
     if (e.p + 119 * sps + half < kWWin) {                    // the last pair (k = 111) has been taken
-      rec_store_bits(my_recs + e.slot, e.ma, e.mb, e.flags, lane);
+      // (its record is normally still in the stage; a list that has been flushed since takes the half record directly)
+      if (STAGED && e.slot >= st.base) stage_store_bits(st, e.slot, e.ma, e.mb, e.flags, lane);
+      else rec_store_bits(st.recs + e.slot, e.ma, e.mb, e.flags, lane);
     } else {
       if (lane == 0) pend->e[keep] = e;
       ++keep;
@@ -671,9 +715,9 @@ __device__ __forceinline__ void pend_step(PendList* pend, int* n_pend, const flo
 }
 
 // End of the wavefront's chunk: what is still pending takes its missing samples from global memory.
-template <int MODE, class CP>
+template <int MODE, bool STAGED, class CP>
 __device__ __forceinline__ void pend_flush(const PendList* pend, int n_pend, WinArgs<CP> a, const float* s_x, long long t0,
-                                           Rec* my_recs, int lane) {
+                                           const Stage& st, int lane) {
   const int sps = a.sps, half = sps >> 1;
   for (int i = 0; i < n_pend; ++i) {
     const PendEntry e = pend->e[i];                          // p relative to t0 (the last tile's start)
@@ -684,7 +728,8 @@ __device__ __forceinline__ void pend_flush(const PendList* pend, int n_pend, Win
     if (ta) { x1 = smp(ja); x0 = smp(ja + half); }
     if (tb) { y1 = smp(jb); y0 = smp(jb + half); }
     const unsigned long long ma = e.ma | __ballot(ta && x1 > x0), mb = e.mb | __ballot(tb && y1 > y0);
-    rec_store_bits(my_recs + e.slot, ma, mb, e.flags, lane);
+    if (STAGED && e.slot >= st.base) stage_store_bits(st, e.slot, ma, mb, e.flags, lane);
+    else rec_store_bits(st.recs + e.slot, ma, mb, e.flags, lane);
   }
 }
 
@@ -864,6 +909,11 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
   __shared__ __attribute__((aligned(16))) unsigned s_ma[kWaves][kMaskDwords];
   __shared__ __attribute__((aligned(4))) unsigned short s_risea[kWaves][kWTile / 2];
   __shared__ PendList s_penda[kWaves];
+  // The output stage is for the formats whose tile loop is bound by HBM (complex64, |IQ|^2 floats, int16: +1-5 %); the 8-bit
+  // formats are bound by their instruction stream, for which the stage is more instructions (-2 ... -5 %): they keep the
+  // store per burst.
+  constexpr bool STAGED = !mode_is_iq8(MODE);
+  __shared__ StageBuf s_stagea[STAGED ? kWaves : 1];
 
   const int lane = threadIdx.x & 63, wave = adsb_uniform((int)(threadIdx.x >> 6));
   float* s_x = s_xa[wave] + kBack;                           // s_x[j] <-> sample t0 + j, j in [-kBack, kWWin)
@@ -887,8 +937,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
   int lp = -1;                                               // per lane: largest paired pulse centre so far, relative to c0
   unsigned med_hint = 0u;                                    // wave-uniform: median key of this wavefront's previous burst
   int pred = adsb_uniform(above_at<MODE>(*cold(), c0 - 1) ? 1 : 0);
-  unsigned long long* my_cands = a.cands + unit * a.rec_cap;
-  Rec* my_recs = a.recs + unit * a.rec_cap;
+  Stage st{&s_stagea[STAGED ? wave : 0], a.recs + unit * a.rec_cap, a.cands + unit * a.rec_cap, 0};
   const float thr = a.thr;
   const bool thr_pos = thr > 0.0f;                           // else (thr <= 0 or NaN): every body takes the exact path
   const int thr_bits = __builtin_bit_cast(int, thr);
@@ -897,7 +946,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
   if (unit == 0 && cold()->scan_lo < 0 && (0.0f >= a.thr) && !(cold()->prev_in0 >= a.thr)) {
     uflags |= 1u;
     if (lane == 0 && 0 < a.rec_cap) {
-      my_cands[0] = cand_make(cold()->scan_lo, kPending | kNoMatch);
+      *(STAGED ? &st.buf->cand[0] : &st.cands[0]) = cand_make(cold()->scan_lo, kPending | kNoMatch);
       const int li = atomicAdd(cold()->long_count, 1);
       if (li < cold()->long_cap) { LongRise e; e.rise = cold()->scan_lo; e.blk = 0; e.slot = 0; cold()->longlist[li] = e; }
     }
@@ -1040,20 +1089,23 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
     for (int m = 0; m < nm; ++m) {
       const int slot2 = nrec + m;
       if (slot2 >= a.rec_cap) break;                     // overflow: reported through the count, call is re-run
+      if (STAGED && slot2 - st.base >= kStage) stage_flush(st, slot2, lane);     // the stage is full: sixteen entries to global memory
+      unsigned long long* const cand_out = STAGED ? &st.buf->cand[slot2 - st.base] : &st.cands[slot2];
+      Rec* const rec_out = STAGED ? &st.buf->rec[slot2 - st.base] : &st.recs[slot2];
       const unsigned e = (unsigned)adsb_uniform((int)s_rise[m]);
       const int v = (int)(e & 0x7FFu);
       if (e & kHitLongPulse) {
         if (lane == 0) {
           const long long rg = t0 + v;
-          my_cands[slot2] = cand_make(rg, kPending | kNoMatch);
+          *cand_out = cand_make(rg, kPending | kNoMatch);
           const int li = atomicAdd(cold()->long_count, 1);
           if (li < cold()->long_cap) { LongRise le; le.rise = rg; le.blk = (int)unit; le.slot = slot2; cold()->longlist[li] = le; }
         }
       } else {
         const bool lh = (e & kHitLongHint) != 0;
-        if (lane == 0) my_cands[slot2] = cand_make(t0 + (long long)v, lh ? kLongHint : 0u);
+        if (lane == 0) *cand_out = cand_make(t0 + (long long)v, lh ? kLongHint : 0u);
         burst_from_window<MODE, EASY>(WinArgs<decltype(cold())>{cold(), a.origin, a.scale, a.sps}, s_x, t0, v,
-                                      lh ? kRecLongHint : 0u, my_recs + slot2, slot2, lane, pend, &n_pend, med_hint);
+                                      lh ? kRecLongHint : 0u, rec_out, slot2, lane, pend, &n_pend, med_hint);
       }
     }
     nrec += nm;
@@ -1069,7 +1121,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
     s_m16[kHeadUnits + lane] = (unsigned short)bm;
     adsb_wave_sync();
     // -- P: bursts met in earlier tiles take the bit samples that have arrived with this body
-    if (n_pend > 0) pend_step(pend, &n_pend, s_x, my_recs, a.sps, half, lane);
+    if (n_pend > 0) pend_step<STAGED>(pend, &n_pend, s_x, st, a.sps, half, lane);
 
     // -- B: rises among the tile's own samples (units 0 .. 63); a tile can hold one only if this or the previous body
     //       had a sample above the threshold (or the sample in front of the tile was)
@@ -1113,7 +1165,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
 
     if (n_pend > 0 && it + 1 == ntile) {                     // end of this wavefront's chunk
       adsb_wave_sync();
-      pend_flush<MODE>(pend, n_pend, WinArgs<decltype(cold())>{cold(), a.origin, a.scale, a.sps}, s_x, t0, my_recs, lane);
+      pend_flush<MODE, STAGED>(pend, n_pend, WinArgs<decltype(cold())>{cold(), a.origin, a.scale, a.sps}, s_x, t0, st, lane);
       n_pend = 0;
     }
     // what the next tile inherits: back + forward halo (floats), the mask units of the forward halo and the last
@@ -1198,6 +1250,8 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
       process_tile(it, t0, true, lane);
     }
   }
+  // what the stage still holds (the whole list of a usual chunk): to global memory, in one go
+  if (STAGED) stage_flush(st, nrec < a.rec_cap ? nrec : a.rec_cap, lane_outer);
   // largest paired pulse centre of the unit: once per unit
 #pragma unroll
   for (int d2 = 32; d2 >= 1; d2 >>= 1) lp = imax(lp, __shfl_xor(lp, d2));

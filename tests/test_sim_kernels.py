@@ -521,3 +521,18 @@ def test_two_tiles_ahead_chunks_of_every_length(fs, bps):
             got, so = simlib.sim_canonical(3, seg, fs, 0.01, grid_max=grid_max, scale=scale)
             assert so.overflow == 0
             assert_recs_equal(got, want, "n %d grid %d" % (n, grid_max))
+
+
+@pytest.mark.parametrize("fs,bps,n", [(20e6, 9000, 3_000_000), (8e6, 9000, 1_500_000), (2e6, 20000, 400_000)])
+def test_output_stage_flushes_in_the_middle_of_a_chunk(fs, bps, n):
+    """Lists far longer than the sixteen-entry LDS stage (adsb_device.h: Stage): dense overlapping replies on four units only --
+    the stage is flushed many times per chunk, bursts longer than the window complete their records after a flush has taken
+    the first half to global memory (20 / 8 Msps), and the last partial stage goes out at the end of the chunk."""
+    sps = int(fs // 1e6)
+    iq = M.synth_iq(n, fs, bps, seed=17 + sps)
+    x = O.mag2(iq)
+    want = C.canonical(x, sps, np.float32(0.01))
+    assert len(want) > 40 * 4
+    got, so = simlib.sim_canonical(1, x, fs, 0.01, grid_max=1)
+    assert so.overflow == 0 and so.n_rec > 40 * 4
+    assert_recs_equal(got, want, "stage")

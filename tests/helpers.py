@@ -203,3 +203,19 @@ def every_byte_pair_stream(scale, slot=256):
         pair[base + 121 + c] = k.astype(np.uint16)
     s2 = np.float32(scale) * np.float32(scale)
     return pair.view(np.int8), np.float32(0.75) * s2
+
+
+def preamble_train_iq(n, spacing=32, sps=2, seed=3):
+    """complex64 IQ: a bare preamble every `spacing` symbols (pulses at chips 0, 2, 7, 9, nothing else -- each one a matched
+    centre, most of them inside the previous one's 63-symbol gate) over a small deterministic noise floor: far more list
+    entries per chunk than any real signal, for the paths that depend on the LENGTH of a unit's list."""
+    rng = np.random.default_rng(seed)
+    a = (rng.random(n, dtype=np.float32) * np.float32(0.02)).astype(np.float32)          # |IQ|^2 <= 4e-4, threshold 0.01
+    half = sps // 2
+    for c in (0, 2, 7, 9):
+        for j in range(half):
+            a[40 * sps + c * half + j::spacing * sps] = np.float32(1.0) + np.float32(0.25) * rng.random(len(a[40 * sps + c * half + j::spacing * sps]), dtype=np.float32)
+    iq = np.zeros(n, dtype=np.complex64)
+    iq.real = a
+    iq.imag = (rng.random(n, dtype=np.float32) * np.float32(0.01)).astype(np.float32)
+    return iq

@@ -6,7 +6,7 @@ import warnings
 import numpy as np
 import pytest
 
-from helpers import (SCHEDULES, Golden, every_byte_pair_stream, assert_recs_equal, assert_recs_match_golden, bulk_golden_names, golden_names,
+from helpers import (SCHEDULES, Golden, every_byte_pair_stream, preamble_train_iq, assert_recs_equal, assert_recs_match_golden, bulk_golden_names, golden_names,
                      large_golden_names, pathological_names, rate_golden_names, schedules_of, snr_bits, unpack)
 
 pytestmark = pytest.mark.gpu
@@ -177,6 +177,27 @@ def test_int8_every_byte_pair_as_peak_and_as_median(native, scale):
     ctx = native.Context(2e6, float(thr))
     ctx.set_format_scale(native.FMT_SC8, float(scale))
     assert_recs_equal(ctx.process_format(native.FMT_SC8, iq8), want, "every byte pair, scale %g" % scale)
+    ctx.close()
+
+
+@pytest.mark.parametrize("sps", [2, 8])
+def test_output_stage_with_lists_of_eighty_entries(native, sps):
+    """k_detect's LDS output stage (adsb_device.h: Stage; complex64, |IQ|^2 floats, int16) holds sixteen records: a train of
+    bare preambles, one every 32 symbols over 2^26 samples, gives every wavefront a list of ~80 (2 Msps) / ~20 (8 Msps)
+    entries on five-tile chunks -- the stage is flushed in the middle of the chunk, at 8 Msps with records whose bits are
+    still arriving (their second half then goes to global memory directly) -- against the C oracle."""
+    from oracle import adsb_oracle as O
+    from oracle import c_oracle as C
+    n = 1 << 26
+    iq = preamble_train_iq(n, sps=sps)
+    x = O.mag2(iq)
+    want = C.canonical(x, sps, np.float32(0.01))
+    assert len(want) >= n // (64 * sps) - 2
+    ctx = native.Context(sps * 1e6, 0.01)
+    assert_recs_equal(ctx.process_iq(iq), want, "stage, complex64")
+    units, per = native.plan_chunks(n, 256 * 5 * 4)
+    assert per >= 4 * 1024 and (n // (32 * sps)) / units > 16, "lists longer than the stage"
+    assert_recs_equal(ctx.process_mag2(x), want, "stage, |IQ|^2")
     ctx.close()
 
 

@@ -591,6 +591,7 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   const int nlists = grid * upb;                           // units past `units` own nothing and report empty lists
   long long rc = (chunk / 256 + 64) << c->rec_cap_shift;
   if (rc > chunk / 2 + 8) rc = chunk / 2 + 8;   // there can never be more rises than that
+  rc = (rc + 15) & ~15ll;                       // every list starts on a 128-byte line (k_detect's output stage writes whole lines)
   s.grid = grid; s.nlists = nlists; s.rec_cap = (int)rc; s.tot = (long long)nlists * rc; s.ntiles = ntiles; s.chunk = chunk;
   const long long long_cap = ntiles + 1;        // at most one long pulse per tile, plus the virtual rise
   int r;

@@ -6,7 +6,13 @@ back in pinned host memory) over one batch of synthetic complex64 IQ that is alr
 N=1 workload: BASELINE.json configs[1] -- synthetic 2 Msps IQ, ~1k DF17 bursts/s.  With N>1 each rank
 owns one overlapped time shard of an N-times longer stream (weak scaling): it detects and gates its own
 shard, the ranks exchange only their 16-byte end-of-burst state, and each fixes up the head of its
-shard on the host (no data-path collective).
+shard on the host (no data-path collective); the same line then carries BASELINE configs[3] -- ONE 20 Msps
+stream tiled as N overlapped shards -- as a weak and a strong scaling leg (`config4_20msps`), each with per-rank
+kernel time / roofline fraction and a seam check.
+
+`--gpus N` is a promise about the line's `n_gpus`: under a launcher (WORLD_SIZE set, as the driver starts it:
+python -m torch.distributed.run --nproc-per-node N ...) the world must be N; started plainly with N > 1 the bench
+starts its own N ranks through the same launcher; anything else exits non-zero -- never a line that says n_gpus: 1.
 
 The timed region is EXACTLY K steps between barrier + synchronize on both sides, max over ranks; it is
 repeated until at least --min-time seconds have been timed (never fewer than 3 repeats) and the MEDIAN
@@ -32,7 +38,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # environment variables the bench knows about; any other ADSB_* variable is refused (a stray tuning knob must never
 # produce an unlabelled number), the known ones are recorded in config.env
-KNOWN_ENV = ("ADSB_BENCH_ONE_GPU", "ADSB_SHARD_EXCHANGE", "ADSB_HIP_LIB")
+KNOWN_ENV = ("ADSB_BENCH_ONE_GPU", "ADSB_SHARD_EXCHANGE", "ADSB_HIP_LIB", "ADSB_BENCH_SPAWNED")
 DF_MIX = ((11, 0, 4, 17, 20, 5, 21), (2335, 1395, 732, 582, 61, 34, 32))   # reference docs/DF_histogram.txt:4-21
 
 
@@ -340,18 +346,23 @@ def format_legs(args, dev, depth):
     base = gen_stream_blocks(n, 0, fs, 1000.0, args.seed, dev)
     torch.cuda.synchronize()
     out = []
+    # int8 twice: scale 2^-5 selects the dot-product instance of k_detect (k_detect<sc8, power-of-two scale>: v_dot4c_i32_i8,
+    # two tiles in flight), scale 4/127 the generic int8 instance (convert, multiply: what any other scale runs)
     for name, fmt, scale in (("mag2", _native.FMT_MAG2, None), ("sc16", _native.FMT_SC16, 4.0 / 32767.0),
-                             ("sc8", _native.FMT_SC8, 4.0 / 128.0), ("cu8", _native.FMT_CU8, 4.0 / 255.0)):
+                             ("sc8", _native.FMT_SC8, 4.0 / 128.0), ("sc8g", _native.FMT_SC8, 4.0 / 127.0),
+                             ("cu8", _native.FMT_CU8, 4.0 / 255.0)):
         fe = FrontEnd(fs, args.threshold, device=dev.index, timing=True)
-        q = quantise_for(fmt, base, fe)
+        q = quantise_for(fmt, base, fe, scale=scale)
         torch.cuda.synchronize()
         ms, times, st, nb, iso_ms = run_single_gpu_config(fe, fmt, q, n, args.extra_steps, 3, args.extra_min_time, depth)
         rec = {"name": "format_" + name, "format": name, "bytes_per_sample": _native.FMT_BYTES[fmt],
                "workload": "BASELINE config 2's signal as %s; 2^%d samples per step resident in HBM" % (
-                   {"mag2": "float32 |IQ|^2", "sc16": "int16 IQ", "sc8": "int8 IQ", "cu8": "uint8 offset-binary IQ"}[name], log2n),
+                   {"mag2": "float32 |IQ|^2", "sc16": "int16 IQ", "sc8": "int8 IQ (scale 2^-5: dot-product instance)",
+                    "sc8g": "int8 IQ (scale 4/127: generic int8 instance)", "cu8": "uint8 offset-binary IQ"}[name], log2n),
+               "kernel_instance": {"sc8": "k_detect<int8, power-of-two scale>", "sc8g": "k_detect<int8, any scale>"}.get(name, "k_detect<%s>" % name),
                "value": round(n / ms / 1e3, 1), "unit": "Msamples/s", "ms_per_step": round(ms, 4), "bursts_per_step": int(nb),
                "roofline": roofline_of(st, name, iso_ms)}
-        tr, tr_src = pmc_traffic(name, fs, 1000.0, False, log2n)
+        tr, tr_src = pmc_traffic("sc8" if name == "sc8g" else name, fs, 1000.0, False, log2n)
         rec["roofline"]["traffic"] = tr
         rec["roofline"]["traffic_source"] = tr_src or "none for this workload (see profiles/)"
         host = q[:cpu_n].cpu().numpy()
@@ -371,10 +382,14 @@ def format_legs(args, dev, depth):
     return out
 
 
-def quantise_for(fmt, iq, fe):
+def quantise_for(fmt, iq, fe, scale=None):
     """The float [n,2] stream quantised to an integer wire format (full scale 4.0); sets the context's matching scale."""
     import torch
     from gr_adsb_amd import _native
+    if fmt == _native.FMT_SC8 and scale is not None and scale != 4.0 / 128.0:
+        # any other int8 scale (here 4/127): the generic int8 instance of k_detect
+        fe.ctx.set_format_scale(fmt, scale)
+        return torch.clamp(torch.round(iq * (1.0 / scale)), -128, 127).to(torch.int8).contiguous()
     if fmt == _native.FMT_SC16:
         fe.ctx.set_format_scale(fmt, 4.0 / 32767.0)
         return torch.clamp(torch.round(iq * (32767.0 / 4.0)), -32768, 32767).to(torch.int16).contiguous()
@@ -518,6 +533,146 @@ def host_fed_all_ranks(args, fe, iq, depth, rank, n_gpus, sync_all, ag_obj):
                       "gbytes_per_s": round(n_gpus * reps * chunk * 8 / max(walls) / 1e9, 2) if ok else None}}
 
 
+class ShardedRun:
+    """One rank's side of the N-rank pipeline: its overlapped time shard resident in HBM, `depth` passes in flight; per pass
+    one device pass over the shard, ONE 16-byte exchange of end-of-burst state and the host fix-up of the shard's head
+    (gr_adsb_amd/sharding.py) -- no data-path collective."""
+
+    def __init__(self, fe, iq, plan, stream_len, sps, rank, ag_int, ag_obj, depth):
+        self.fe, self.iq, self.plan, self.stream_len, self.sps, self.rank = fe, iq, plan, stream_len, sps, rank
+        self.ag_int, self.ag_obj, self.depth = ag_int, ag_obj, depth
+        self.pending, self.stash = [], {}      # tickets in flight; results of tickets collected early (fallback path only)
+        self.last_kept, self.last_n, self.stitch_s, self.passes = None, 0, 0.0, 0
+
+    def step(self):
+        from gr_adsb_amd import sharding
+        p = self.plan
+        self.pending.append(self.fe.submit_shard_tensor(self.iq, p["lo"], p["own_lo"], p["own_hi"], self.stream_len,
+                                                        head_cands=sharding.HEAD_CANDS))
+        if len(self.pending) == self.depth:
+            self._collect(self.pending.pop(0))
+
+    def drain(self):
+        while self.pending:
+            self._collect(self.pending.pop(0))
+        return self.last_n
+
+    def _ungated(self):
+        # fallback of sharding.finish_shard: a blocking call is only allowed with no ticket pending, so collect (and keep)
+        # whatever is still in flight first; every rank takes this path together
+        for t in list(self.pending):
+            self.stash[t] = self.fe.wait(t)
+        p = self.plan
+        return self.fe.shard_tensor(self.iq, p["lo"], p["own_lo"], p["own_hi"], self.stream_len)
+
+    def _collect(self, ticket):
+        from gr_adsb_amd import sharding
+        if ticket in self.stash:
+            recs, inplace = self.stash.pop(ticket), False
+        else:
+            recs, inplace = self.fe.wait(ticket, copy=False), True      # view of the pinned result buffer, fixed up in place
+        t_x = time.perf_counter()
+        kept = sharding.finish_shard(recs, self.sps, self.rank, self.ag_int, self._ungated, self.ag_obj, inplace=inplace)
+        self.stitch_s += time.perf_counter() - t_x
+        self.passes += 1
+        self.last_kept, self.last_n = kept, len(kept)
+
+
+def sharded_leg(args, dev, rank, n_gpus, fs, bursts, seed, n_own, steps, warmup, min_time, depth, sync_all, reduce_max,
+                ag_int, ag_obj, synth, fe=None, extra_me=None):
+    """One stream of n_own * n_gpus samples tiled as n_gpus overlapped time shards, one per rank; returns this rank's view
+    (every rank gets the same dict: times are max over ranks, per_rank and the seam check are gathered)."""
+    import torch
+    from gr_adsb_amd import sharding
+    from gr_adsb_amd.frontend import FrontEnd, shard_plan
+    sps = int(fs // 1e6)
+    stream_len = n_own * n_gpus
+    if fe is None:
+        fe = FrontEnd(fs, args.threshold, device=dev.index, timing=True)
+    plan = shard_plan(stream_len, n_gpus, sps, align=n_own)[rank]
+    iq = gen_stream_blocks(plan["hi"] - plan["lo"], plan["lo"], fs, bursts, seed, dev, **synth)
+    torch.cuda.synchronize()
+    run = ShardedRun(fe, iq, plan, stream_len, sps, rank, ag_int, ag_obj, depth)
+    fb0 = sharding.STATS["fallbacks"]
+    for _ in range(warmup):
+        run.step()
+    run.drain()
+    fe.ctx.reset_stats()
+    own_times = []
+
+    def reduce_and_keep(t):
+        own_times.append(t)
+        return reduce_max(t)
+
+    times, n_bursts = timed_repeats(run.step, run.drain, sync_all, reduce_and_keep, steps, min_time)
+    st = fe.stats()
+    numa = fe.ctx.numa_info()
+    kern_ms = st["detect_ms"] / max(1, st["detect_launches"])
+    alg = st["detect_bytes"] / max(1, st["detect_launches"])
+    me = {"rank": rank, "device": torch.cuda.current_device(),
+          "pci_bus_id": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None) or numa["pci"],
+          "ms_per_step_min": round(min(own_times) / steps * 1e3, 4), "ms_per_step_max": round(max(own_times) / steps * 1e3, 4),
+          "kernel_ms": round(kern_ms, 4),
+          "roofline_frac": round(alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern_ms > 0 else None,
+          "shard_samples": int(plan["hi"] - plan["lo"]),
+          "stitch_ms_per_step": round(run.stitch_s / max(1, run.passes) * 1e3, 4),
+          "stitch_fallbacks": sharding.STATS["fallbacks"] - fb0, "bursts_per_step": int(n_bursts),
+          "numa_node": numa["node"], "local_cpulist": numa["cpulist"]}
+    me.update(extra_me or {})
+    per_rank = ag_obj(me)
+    seam = seam_check(args, fe, dev, rank, n_gpus, sps, n_own, stream_len, run.last_kept, ag_obj, fs=fs, bursts=bursts,
+                      seed=seed, synth=synth)
+    elapsed = float(np.median(times))
+    return {"fs": fs, "n_own": n_own, "stream_len": stream_len, "times": times, "elapsed": elapsed, "stats": st,
+            "value": round(float(stream_len) * steps / elapsed / 1e6, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "n_bursts": int(n_bursts), "per_rank": per_rank, "seam": seam, "fe": fe, "iq": iq}
+
+
+def config4_legs(args, dev, rank, n_gpus, depth, sync_all, reduce_max, ag_int, ag_obj, rank_sync):
+    """BASELINE configs[3] with N ranks: ONE 20 Msps stream tiled as N overlapped time shards, host stitch.  Two legs:
+    `weak` (2^log2n samples per GPU: the stream grows with N) and `strong` (2^log2n samples in total: every GPU gets 1/N),
+    each with per-rank kernel time / roofline fraction and its own seam check."""
+    import torch
+    out = {"workload": "synthetic 20 Msps complex64 IQ, 1000 DF17-length bursts/s, AWGN 1e-3, seed 3: one stream tiled as %d "
+                       "overlapped time shards (one per GPU), heads re-gated on the host after one 16-byte exchange" % n_gpus,
+           "fs": 20e6, "rank_sync": rank_sync}
+    fe = None
+    for name, n_own in (("weak", 1 << args.log2n), ("strong", max(1 << 22, (1 << args.log2n) // n_gpus))):
+        leg = sharded_leg(args, dev, rank, n_gpus, 20e6, 1000.0, 3, n_own, args.extra_steps, 3, args.extra_min_time, depth,
+                          sync_all, reduce_max, ag_int, ag_obj, {}, fe=fe)
+        fe = leg["fe"]
+        out[name] = {"scaling": name, "samples_per_gpu_per_step": n_own, "stream_samples_per_step": leg["stream_len"],
+                     "value": leg["value"], "unit": "Msamples/s", "ms_per_step": leg["ms_per_step"], "steps": args.extra_steps,
+                     "repeats": len(leg["times"]), "bursts_per_step_rank0": leg["n_bursts"],
+                     "hbm_frac_whole_job": round(8.0 * leg["stream_len"] / (leg["ms_per_step"] * 1e-3) / 1e9 / (HBM_PEAK_GBS * n_gpus), 4),
+                     "per_rank": leg["per_rank"], "seam_check": leg["seam"],
+                     "stitch_fallbacks_total": int(sum(r["stitch_fallbacks"] for r in leg["per_rank"]))}
+        del leg
+        torch.cuda.empty_cache()
+    return out
+
+
+def _free_port():
+    import socket
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    return port
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started plainly (no launcher around it: WORLD_SIZE unset): start the N ranks ourselves,
+    exactly as the driver's launcher would -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N on 127.0.0.1 --
+    pass every argument through, hand rank 0's JSON line on and return the launcher's exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), ADSB_BENCH_SPAWNED="1")
+    print("bench.py: --gpus %d without a launcher: starting the ranks with %s" % (n, " ".join(cmd[1:9])), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -541,6 +696,8 @@ def main():
     ap.add_argument("--host-fed", action="store_true", help="(kept for compatibility: with --gpus N > 1 the PCIe-inclusive leg runs by default)")
     ap.add_argument("--no-host-fed-multi", action="store_true",
                     help="with --gpus N > 1: skip the PCIe-inclusive leg (every rank feeding its GPU from page-locked host memory)")
+    ap.add_argument("--no-config4", action="store_true",
+                    help="with --gpus N > 1: skip BASELINE config 4's legs (one 20 Msps stream tiled as N overlapped shards, weak and strong)")
     ap.add_argument("--mixed-df", action="store_true",
                     help="BASELINE config 5's signal as the main workload: DF mix of docs/DF_histogram.txt, SNR 3-25 dB over noise 2e-3")
     ap.add_argument("--force-dist", action="store_true",
@@ -563,10 +720,23 @@ def main():
         return 2
     env_known = {k: os.environ[k] for k in KNOWN_ENV if k in os.environ}
 
+    # --gpus N is a promise about the line's n_gpus.  Under a launcher (WORLD_SIZE set) the world must BE N; started plainly
+    # with N > 1 the bench starts its own N ranks; anything else is an error -- never a line that says n_gpus: 1.
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("bench.py: launched with WORLD_SIZE=%d but --gpus %d: refusing to print a line for the wrong number of GPUs "
+              "(use --nproc-per-node %d, or start `python bench.py --gpus %d` without a launcher)"
+              % (world, args.gpus, args.gpus, args.gpus), file=sys.stderr)
+        return 2
+
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # ADSB_BENCH_ONE_GPU=1: debugging aid -- run the N-rank code path with every rank on cuda:0 (gloo only)
@@ -578,8 +748,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="gloo" if one_gpu else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
         host_group = dist.new_group(backend="gloo")
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
     n_gpus = world
+    if not one_gpu and not args.force_dist and n_gpus > torch.cuda.device_count():
+        print("bench.py: --gpus %d but this node shows %d GPU(s) (ADSB_BENCH_ONE_GPU=1 runs every rank on cuda:0 for debugging)"
+              % (n_gpus, torch.cuda.device_count()), file=sys.stderr)
+        if dist_on:
+            dist.destroy_process_group()
+        return 2
     if one_gpu:
         local_rank = 0
     elif args.force_dist:
@@ -588,12 +763,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from gr_adsb_amd import _native, sharding
-    from gr_adsb_amd.frontend import FrontEnd, shard_plan
+    from gr_adsb_amd.frontend import FrontEnd
 
     fs = args.fs
     sps = int(fs // 1e6)
     n_own = 1 << args.log2n
-    stream_len = n_own * n_gpus
     fe = FrontEnd(fs, args.threshold, device=local_rank, timing=True,
                   flags=(_native.FLAG_SINGLE_STREAM if args.single_stream else 0) | (_native.FLAG_LOW_LATENCY if args.low_latency else 0))
     # one process per GPU: run this rank's host side on the cpus local to its GPU (the library already places its pinned
@@ -614,58 +788,14 @@ def main():
     intfmt = args.format != "fc32"
     fmt = {"fc32": _native.FMT_FC32, "mag2": _native.FMT_MAG2, "sc16": _native.FMT_SC16, "sc8": _native.FMT_SC8,
            "cu8": _native.FMT_CU8}[args.format]
-    assert not (intfmt and n_gpus > 1)
+    if intfmt and n_gpus > 1:
+        print("bench.py: --format %s is an N=1 leg" % args.format, file=sys.stderr)
+        if dist_on:
+            dist.destroy_process_group()
+        return 2
     synth = dict(noise_power=2e-3, df_choices=DF_MIX[0], df_weights=DF_MIX[1], snr_db_range=(3.0, 25.0)) if args.mixed_df else {}
-    if n_gpus == 1:
-        iq = gen_stream_blocks(n_own, 0, fs, args.bursts, args.seed, dev, **synth)
-        plan = None
-        # quantise the same stream to the integer wire format (full scale 4.0); the kernel converts with the same scale
-        # |IQ|^2 of the same stream (separately rounded products, SURVEY §8a H0) / the stream quantised to the integer wire
-        # format (full scale 4.0; the kernel converts with the same scale), computed once outside the timed region
-        iq = quantise_for(fmt, iq, fe)
-    else:
-        plan = shard_plan(stream_len, n_gpus, sps, align=n_own)[rank]
-        iq = gen_stream_blocks(plan["hi"] - plan["lo"], plan["lo"], fs, args.bursts, args.seed, dev, **synth)
-    torch.cuda.synchronize()
 
     DEPTH = min(args.depth, _native.MAX_IN_FLIGHT) if args.depth > 0 else _native.MAX_IN_FLIGHT
-    pending = []          # tickets of submitted, not yet collected passes (pipeline of DEPTH passes)
-    host_t = {"stitch": 0.0}
-    stash = {}            # results of tickets that had to be collected early (fallback path only)
-    last_kept = [None]    # N>1: this rank's exact kept bursts of the last collected pass (seam check)
-
-    def step():
-        if n_gpus == 1:
-            # submit pass i+1 before collecting pass i: the PCIe copy and host work of one pass overlap the
-            # kernels of the next; every pass is collected inside the timed region (drain() below)
-            pending.append(fe.submit_format_tensor(fmt, iq, 0))
-            if len(pending) == DEPTH:
-                last_n[0] = fe.wait(pending.pop(0), fetch=False)
-            return 0
-        # N>1: same DEPTH-deep pipeline; the host stitch of pass i (one 16-byte exchange) overlaps the GPU passes after it
-        pending.append(fe.submit_shard_tensor(iq, plan["lo"], plan["own_lo"], plan["own_hi"], stream_len,
-                                              head_cands=sharding.HEAD_CANDS))
-        if len(pending) == DEPTH:
-            last_n[0] = collect_shard(pending.pop(0))
-        return 0
-
-    def ungated():
-        # fallback of sharding.finish_shard: a blocking call is only allowed with no ticket pending, so
-        # collect (and keep) whatever is still in flight first; every rank takes this path together
-        for t in list(pending):
-            stash[t] = fe.wait(t)
-        return fe.shard_tensor(iq, plan["lo"], plan["own_lo"], plan["own_hi"], stream_len)
-
-    def collect_shard(ticket):
-        if ticket in stash:
-            recs, inplace = stash.pop(ticket), False
-        else:
-            recs, inplace = fe.wait(ticket, copy=False), True    # view of the pinned result buffer, fixed up in place
-        t_x = time.perf_counter()
-        kept = sharding.finish_shard(recs, sps, rank, ag_int, ungated, ag_obj, inplace=inplace)
-        host_t["stitch"] += time.perf_counter() - t_x
-        last_kept[0] = kept
-        return len(kept)
 
     # 16 bytes per rank per pass, host side: shared-memory mailbox on one node, gloo all_gather across nodes
     ag_int, ag_close = sharding.make_pair_exchange(dist, rank, n_gpus, group=host_group) if n_gpus > 1 else (None, lambda: None)
@@ -675,13 +805,6 @@ def main():
         out = [None] * n_gpus
         dist.all_gather_object(out, o, group=host_group)
         return out
-
-    last_n = [0]
-
-    def drain():
-        while pending:
-            last_n[0] = fe.wait(pending.pop(0), fetch=False) if n_gpus == 1 else collect_shard(pending.pop(0))
-        return last_n[0]
 
     # barrier / max-over-ranks go over RCCL (backend "nccl") on the GPUs; if the communicator cannot be set up on
     # this node they fall back to the gloo side of the same process group rather than losing the run
@@ -714,45 +837,59 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=sync_group())
         return float(tmax.item())
 
-    # a few blocking passes in front of everything (they also bring a fresh box's clocks up)
+    rank_sync = None if not dist_on else ("gloo" if sync_dev[0] == "cpu" else "rccl")
+    per_rank = seam = hf_multi = cfg4 = None
+    iso_ms = untimed = None
     if n_gpus == 1:
+        iq = gen_stream_blocks(n_own, 0, fs, args.bursts, args.seed, dev, **synth)
+        # |IQ|^2 of the same stream (separately rounded products, SURVEY §8a H0) / the stream quantised to the integer wire
+        # format (full scale 4.0; the kernel converts with the same scale), computed once outside the timed region
+        iq = quantise_for(fmt, iq, fe)
+        torch.cuda.synchronize()
+        pending = []          # tickets of submitted, not yet collected passes (pipeline of DEPTH passes)
+        last_n = [0]
+
+        def step():
+            # submit pass i+1 before collecting pass i: the PCIe copy and host work of one pass overlap the
+            # kernels of the next; every pass is collected inside the timed region (drain() below)
+            pending.append(fe.submit_format_tensor(fmt, iq, 0))
+            if len(pending) == DEPTH:
+                last_n[0] = fe.wait(pending.pop(0), fetch=False)
+
+        def drain():
+            while pending:
+                last_n[0] = fe.wait(pending.pop(0), fetch=False)
+            return last_n[0]
+
+        # a few blocking passes in front of everything (they also bring a fresh box's clocks up)
         for _ in range(6):
             fe.ctx.process_format_device(fmt, iq.data_ptr(), n_own, 0, fetch=False)
-
-    for _ in range(args.warmup):
-        step()
-    drain()
-    fe.ctx.reset_stats()
-    own_times = []
-
-    def reduce_and_keep(t):
-        own_times.append(t)
-        return reduce_max(t)
-
-    times, n_bursts = timed_repeats(step, drain, sync_all, reduce_and_keep, args.steps, args.min_time)
-    elapsed = float(np.median(times))
-    st = fe.stats()
-    # the same kernel timed without a neighbour, AFTER the timed region
-    iso_ms = isolated_kernel_ms(fe, fmt, iq, n_own) if n_gpus == 1 else None
-
-    # every rank reports; rank 0 prints (N>1: the record says what each rank saw)
-    per_rank = None
-    seam = None
-    if n_gpus > 1:
-        me = {"rank": rank, "device": torch.cuda.current_device(), "pci_bus_id": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None),
-              "ms_per_step_min": round(min(own_times) / args.steps * 1e3, 4), "ms_per_step_max": round(max(own_times) / args.steps * 1e3, 4),
-              "kernel_ms": round(st["detect_ms"] / max(1, st["detect_launches"]), 4),
-              "stitch_ms_per_step": round(host_t["stitch"] / max(1, args.steps * len(times) + args.warmup) * 1e3, 4),
-              "stitch_fallbacks": sharding.STATS["fallbacks"], "bursts_per_step": int(n_bursts),
-              "numa_node": numa["node"], "local_cpulist": numa["cpulist"], "process_bound_to_local_cpus": numa["bound"]}
-        per_rank = ag_obj(me)
+        for _ in range(args.warmup):
+            step()
+        drain()
+        fe.ctx.reset_stats()
+        times, n_bursts = timed_repeats(step, drain, sync_all, reduce_max, args.steps, args.min_time)
+        st = fe.stats()
+        # the same kernel timed without a neighbour, AFTER the timed region
+        iso_ms = isolated_kernel_ms(fe, fmt, iq, n_own)
+        # ... and the same pipeline on a context WITHOUT ADSB_FLAG_TIMING (the product default: no event pair between
+        # consecutive k_detect launches), a few repeats right behind the timed ones
+        untimed = untimed_context_ms(args, local_rank, fmt, iq, n_own, DEPTH, sync_all)
+    else:
+        leg = sharded_leg(args, dev, rank, n_gpus, fs, args.bursts, args.seed, n_own, args.steps, args.warmup, args.min_time,
+                          DEPTH, sync_all, reduce_max, ag_int, ag_obj, synth, fe=fe,
+                          extra_me={"process_bound_to_local_cpus": numa["bound"]})
+        times, n_bursts, st, per_rank, seam, iq = leg["times"], leg["n_bursts"], leg["stats"], leg["per_rank"], leg["seam"], leg["iq"]
         if not one_gpu and not args.force_dist:
             assert len({r["device"] for r in per_rank}) == n_gpus or len({r["pci_bus_id"] for r in per_rank}) == n_gpus, \
                 "ranks share a GPU (set ADSB_BENCH_ONE_GPU=1 if that is intended)"
-        seam = seam_check(args, fe, dev, rank, n_gpus, sps, n_own, stream_len, last_kept[0], ag_obj)
-    hf_multi = None
-    if n_gpus > 1 and not args.no_host_fed_multi:
-        hf_multi = host_fed_all_ranks(args, fe, iq, DEPTH, rank, n_gpus, sync_all, ag_obj)
+        if not args.no_host_fed_multi:
+            hf_multi = host_fed_all_ranks(args, fe, iq, DEPTH, rank, n_gpus, sync_all, ag_obj)
+        del leg, iq
+        torch.cuda.empty_cache()
+        if not args.no_config4:
+            cfg4 = config4_legs(args, dev, rank, n_gpus, DEPTH, sync_all, reduce_max, ag_int, ag_obj, rank_sync)
+    elapsed = float(np.median(times))
 
     result = None
     if rank == 0:
@@ -785,7 +922,9 @@ def main():
                                "AWGN 2e-3" if args.mixed_df else "AWGN 1e-3", args.threshold, args.log2n),
                 "fs": fs, "samples_per_gpu_per_step": n_own, "bursts_per_step_rank0": int(n_bursts),
                 "sharding": "none" if n_gpus == 1 else "%d overlapped time shards, host stitch" % n_gpus,
-                "rank_sync": None if not dist_on else ("gloo" if sync_dev[0] == "cpu" else "rccl"),
+                "rank_sync": rank_sync,
+                "launched_by": "bench.py itself (torch.distributed.run)" if os.environ.get("ADSB_BENCH_SPAWNED") == "1" else (
+                    "external launcher" if "WORLD_SIZE" in os.environ else "plain process"),
                 "pipeline": "%d passes in flight (submit/wait)%s" % (DEPTH, (", single stream" if args.single_stream else "") + (", low-latency tail" if args.low_latency else "")),
                 "detect_gap_ms_avg": round(st["detect_gap_ms"] / max(1, st["detect_gaps"]), 4),
                 "detect_grid": int(st["detect_grid"]), "retries": int(st["retries"]), "longrun_calls": int(st["longrun_calls"]),
@@ -795,16 +934,22 @@ def main():
             },
             "roofline": roofline_of(st, args.format, iso_ms),
         }
+        if untimed is not None:
+            result["timing"]["ms_per_step_untimed_ctx"] = untimed["ms_per_step"]
+            result["timing"]["untimed_ctx"] = untimed
         result["roofline"]["kernel_only_msamples_per_s"] = round(
             st["detect_samples"] / max(1, st["detect_launches"]) / (result["roofline"]["kernel_ms"] * 1e-3) / 1e6, 1)
         result["roofline"]["traffic"] = traffic
         result["roofline"]["traffic_source"] = traffic_src or "none for this workload (see profiles/)"
         if n_gpus > 1:
+            result["roofline"]["note"] = "rank 0's k_detect over its own shard; every rank's figure is in multi_gpu.per_rank"
             result["multi_gpu"] = {"ranks_seen": len(per_rank), "exchange_transport": transport, "per_rank": per_rank,
                                    "stitch_fallbacks_total": int(sum(r["stitch_fallbacks"] for r in per_rank)),
                                    "seam_check": seam}
             if hf_multi is not None:
                 result["host_fed"] = hf_multi
+            if cfg4 is not None:
+                result["config4_20msps"] = cfg4
         if not args.no_cpu and n_gpus == 1 and not intfmt:
             n_cpu = min(n_own, 1 << args.cpu_log2n)
             host = iq[:n_cpu].cpu().numpy().view(np.complex64).reshape(-1)
@@ -852,6 +997,8 @@ def main():
             cfgd["bit_match_identical"] = bool(result["bit_match"]["identical"])
             cfgd["bit_match_bursts"] = int(result["bit_match"]["sample_bursts"])
         cfgd["roofline_frac_isolated"] = (result["roofline"].get("isolated") or {}).get("frac")
+        if untimed is not None:
+            cfgd["ms_per_step_untimed_ctx"] = untimed["ms_per_step"]
         for rec in result.get("extra_configs", []) + result.get("formats", []):
             key = rec["name"].split("_")[0].replace("config", "cfg") if rec["name"].startswith("config") else rec["format"]
             cfgd[key + "_frac"] = rec["roofline"]["frac"]
@@ -864,11 +1011,19 @@ def main():
         for name, rec in hf.items():
             cfgd["hostfed_%s_pinned_msps" % name] = rec["pinned"]["value"]
             cfgd["hostfed_%s_pageable_msps" % name] = rec["pageable"]["value"]
+            cfgd["hostfed_%s_pinned_vs_plain_h2d" % name] = rec["pinned_vs_plain_h2d"]
         if n_gpus > 1 and result.get("multi_gpu"):
             cfgd["seams_identical"] = bool(result["multi_gpu"]["seam_check"]["all_identical"])
             cfgd["stitch_fallbacks"] = int(result["multi_gpu"]["stitch_fallbacks_total"])
+            cfgd["per_rank_roofline_frac"] = [r_["roofline_frac"] for r_ in per_rank]
             if result.get("host_fed", {}).get("total"):
                 cfgd["hostfed_total_msps"] = result["host_fed"]["total"]["value"]
+            if cfg4 is not None:
+                for leg_name in ("weak", "strong"):
+                    cfgd["cfg4_%s_msps" % leg_name] = cfg4[leg_name]["value"]
+                    cfgd["cfg4_%s_ms" % leg_name] = cfg4[leg_name]["ms_per_step"]
+                    cfgd["cfg4_%s_seams_identical" % leg_name] = bool(cfg4[leg_name]["seam_check"]["all_identical"])
+                    cfgd["cfg4_%s_per_rank_frac" % leg_name] = [r_["roofline_frac"] for r_ in cfg4[leg_name]["per_rank"]]
         print(json.dumps(result), flush=True)
     if n_gpus > 1:
         sync_all()
@@ -878,7 +1033,38 @@ def main():
     return result
 
 
-def seam_check(args, fe, dev, rank, n_gpus, sps, n_own, stream_len, kept, ag_obj):
+def untimed_context_ms(args, device, fmt, iq, n, depth, sync_all, repeats=3):
+    """The headline pipeline on a context created WITHOUT ADSB_FLAG_TIMING -- the product default: no HIP event pair between
+    consecutive k_detect launches.  Same buffer, same depth, `steps` steps per repeat, median of a few repeats."""
+    from gr_adsb_amd.frontend import FrontEnd
+    fe2 = FrontEnd(args.fs, args.threshold, device=device, timing=False,
+                   flags=0)
+    if fmt not in (0, 1):
+        # the integer wire formats convert with the scale the timed context was given (quantise_for)
+        from gr_adsb_amd import _native
+        fe2.ctx.set_format_scale(fmt, {_native.FMT_SC16: 4.0 / 32767.0, _native.FMT_SC8: 4.0 / 128.0, _native.FMT_CU8: 4.0 / 255.0}[fmt])
+    pend = []
+    for _ in range(3):
+        fe2.ctx.process_format_device(fmt, iq.data_ptr(), n, 0, fetch=False)
+    tt, nb = [], 0
+    for _ in range(repeats):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pend.append(fe2.submit_format_tensor(fmt, iq, 0))
+            if len(pend) == depth:
+                nb = fe2.wait(pend.pop(0), fetch=False)
+        while pend:
+            nb = fe2.wait(pend.pop(0), fetch=False)
+        sync_all()
+        tt.append((time.perf_counter() - t0) / args.steps * 1e3)
+    fe2.ctx.close()
+    return {"ms_per_step": round(float(np.median(tt)), 4), "repeats": repeats, "steps_per_repeat": args.steps,
+            "bursts_per_step": int(nb), "msamples_per_s": round(n / float(np.median(tt)) / 1e3, 1),
+            "note": "same buffer and depth on a context without ADSB_FLAG_TIMING (no event pair between k_detect launches)"}
+
+
+def seam_check(args, fe, dev, rank, n_gpus, sps, n_own, stream_len, kept, ag_obj, fs=None, bursts=None, seed=None, synth=None):
     """N>1 exactness evidence at full size: around every shard seam, ONE canonical call over a window that straddles
     the seam (regenerated from the deterministic stream) must report exactly the bursts the two neighbouring ranks
     reported there.  The window call starts from fresh state half a window before the compared region; it re-joins
@@ -896,7 +1082,8 @@ def seam_check(args, fe, dev, rank, n_gpus, sps, n_own, stream_len, kept, ag_obj
     if rank >= 1:
         s = rank * n_own
         import torch
-        win = gen_stream_blocks(2 * W, s - W, args.fs, args.bursts, args.seed, dev)
+        win = gen_stream_blocks(2 * W, s - W, args.fs if fs is None else fs, args.bursts if bursts is None else bursts,
+                                args.seed if seed is None else seed, dev, **(synth or {}))
         torch.cuda.synchronize()                                   # torch produced it; the context runs on its own stream
         recs = fe.process_iq_tensor(win, s - W)
         recs = recs[(recs["offset"] >= lo_cmp(s)) & (recs["offset"] < hi_cmp(s))]

@@ -21,7 +21,7 @@ FLAG_SINGLE_STREAM = 8    # profiling aid: the sparse tail of a pass on the comp
 FLAG_FRAMER_SLICES = 32   # adsb_framer_work also returns the 112 bits of tags whose burst ends inside the call's input
 FLAG_NO_NUMA_BINDING = 64 # host side not placed on the GPU's NUMA node (default: page-locked buffers and copy threads are)
 FLAG_LOW_LATENCY = 16     # the tail of a pass runs beside the next pass's k_detect: results a pass earlier, 1-2 % less throughput
-ABI_VERSION = 2
+ABI_VERSION = 3
 # input sample formats (include/adsb_hip.h ADSB_FMT_*): numpy dtype of the flat host array, items per sample
 FMT_FC32, FMT_MAG2, FMT_SC16, FMT_SC8, FMT_CU8 = 0, 1, 2, 3, 4
 FMT_LAYOUT = {FMT_FC32: (np.complex64, 1), FMT_MAG2: (np.float32, 1), FMT_SC16: (np.int16, 2), FMT_SC8: (np.int8, 2),
@@ -52,7 +52,8 @@ class Stats(ctypes.Structure):
     _fields_ = [("detect_launches", ctypes.c_uint64), ("detect_ms", ctypes.c_double), ("detect_samples", ctypes.c_uint64),
                 ("detect_bytes", ctypes.c_uint64), ("calls", ctypes.c_uint64), ("retries", ctypes.c_uint64),
                 ("longrun_calls", ctypes.c_uint64), ("detect_grid", ctypes.c_uint64), ("blocks_per_cu", ctypes.c_uint64),
-                ("detect_gap_ms", ctypes.c_double), ("detect_gaps", ctypes.c_uint64), ("longrun_pulses", ctypes.c_uint64)]
+                ("detect_gap_ms", ctypes.c_double), ("detect_gaps", ctypes.c_uint64), ("longrun_pulses", ctypes.c_uint64),
+                ("poll_fallbacks", ctypes.c_uint64)]
 
 
 class AdsbError(RuntimeError):

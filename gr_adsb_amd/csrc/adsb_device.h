@@ -439,7 +439,10 @@ __device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, fl
   float med;
   if (nwin == 0) med = __builtin_bit_cast(float, 0xFFC00000u);       // np.median([]) == 0/0: default NaN, sign set
   else if (nanm) med = __builtin_bit_cast(float, 0x7FC00000u);        // a NaN in the window propagates
-  else if (nwin & 1) med = key_f32(A);
+  // (a median of zero is +0.0 whatever the signs of the zeros in the window: np.median is np.mean of the middle element(s),
+  // whose sum starts from +0.0 -- 0.0 + -0.0 = +0.0 -- so the result never depends on how -0.0 and +0.0 were ordered; the
+  // key order here puts -0.0 below +0.0, the rounded add of +0.0 below makes that invisible.  x + 0.0 == x for every other x)
+  else if (nwin & 1) med = __fadd_rn(key_f32(A), 0.0f);
   else {
     // upper middle: A again if it occurs often enough (impossible when A was alone in its interval), else the
     // smallest key above A
@@ -451,7 +454,7 @@ __device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, fl
       if (k1 > A && k1 < m) m = k1;
       B = adsb_wave_min_u32(m);
     }
-    med = __fmul_rn(__fadd_rn(key_f32(A), key_f32(B)), 0.5f);          // f32(a+b)/2
+    med = __fadd_rn(__fmul_rn(__fadd_rn(key_f32(A), key_f32(B)), 0.5f), 0.0f);          // f32(a+b)/2
   }
   return med;
 }
@@ -1751,7 +1754,13 @@ struct TailArgs {
 // fence, so that the records compact_body stored straight into pinned host memory and the summary's fields are visible
 // first -- the pass number.  The host does not wait for the kernel's completion signal (end-of-kernel cache maintenance,
 // signal, the runtime's wake-up: several microseconds of a call that costs 25): it polls that word.
+// The records were stored by EVERY wavefront of the workgroup: each thread fences its own stores to system scope (the
+// fence waits for the thread's outstanding stores to be acknowledged and writes them through) BEFORE the workgroup
+// barrier -- a workgroup barrier alone orders them at workgroup scope only, and thread 0's fence below would cover
+// thread 0's stores, not the other wavefronts'.
 __device__ __forceinline__ void publish_small(const TailArgs& t) {
+  __threadfence_system();
+  __syncthreads();
   if (threadIdx.x == 0) {
     Summary f = *t.sum;
     f.pad_ = 0;

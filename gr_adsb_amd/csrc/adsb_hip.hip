@@ -331,6 +331,17 @@ struct adsb_ctx {
 
 namespace {
 
+// one polite iteration of a host spin loop
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#else
+  std::this_thread::yield();
+#endif
+}
+
 int fail(adsb_ctx* c, int code, const char* what, hipError_t he = hipSuccess) {
   if (c) {
     if (he != hipSuccess) snprintf(c->err, sizeof(c->err), "%s: %s", what, hipGetErrorString(he));
@@ -358,15 +369,27 @@ int ensure(adsb_ctx* c, DevBuf& b, size_t bytes) {
 // node for the duration of the allocation (raw set_mempolicy: no libnuma in the image) and hipHostMallocNumaUser tells HIP
 // to honour it.  Without a known node (numa_node < 0: single-socket host, or sysfs not visible) a plain allocation.
 constexpr int kMpolDefault = 0, kMpolPreferred = 1;
-hipError_t host_alloc_near(adsb_ctx* c, void** p, size_t bytes) {
-  if (!c || c->numa_node < 0 || c->numa_node >= 1024) return hipHostMalloc(p, bytes, hipHostMallocDefault);
+// `coherent`: the buffer is read by the HOST while the kernel that writes it may still be running (the polled summary and
+// the records of a one-workgroup pass): asked for explicitly as fine-grained memory (hipHostMallocCoherent) instead of
+// relying on the runtime's default / HIP_HOST_COHERENT.
+hipError_t host_alloc_near(adsb_ctx* c, void** p, size_t bytes, bool coherent = false) {
+  const unsigned co = coherent ? hipHostMallocCoherent : 0u;
+  if (!c || c->numa_node < 0 || c->numa_node >= 1024) {
+    hipError_t e0 = hipHostMalloc(p, bytes, hipHostMallocDefault | co);
+    if (e0 != hipSuccess && co) { (void)hipGetLastError(); e0 = hipHostMalloc(p, bytes, hipHostMallocDefault); }
+    return e0;
+  }
   unsigned long mask[16] = {0}, old_mask[16] = {0};
   mask[c->numa_node / (8 * sizeof(unsigned long))] |= 1ul << (c->numa_node % (8 * sizeof(unsigned long)));
   // the caller's own policy is put back afterwards (whatever it was)
   int old_mode = kMpolDefault;
   const bool have_old = syscall(SYS_get_mempolicy, &old_mode, old_mask, sizeof(old_mask) * 8, nullptr, 0) == 0;
   const long rc = syscall(SYS_set_mempolicy, kMpolPreferred, mask, sizeof(mask) * 8);
-  hipError_t e = hipHostMalloc(p, bytes, rc == 0 ? hipHostMallocNumaUser : hipHostMallocDefault);
+  hipError_t e = hipHostMalloc(p, bytes, (rc == 0 ? hipHostMallocNumaUser : hipHostMallocDefault) | co);
+  if (e != hipSuccess && co) {                       // (a runtime that refuses the combination: placement first)
+    (void)hipGetLastError();
+    e = hipHostMalloc(p, bytes, rc == 0 ? hipHostMallocNumaUser : hipHostMallocDefault);
+  }
   if (rc == 0) {
     if (!have_old || old_mode == kMpolDefault || syscall(SYS_set_mempolicy, old_mode, old_mask, sizeof(old_mask) * 8) != 0)
       (void)syscall(SYS_set_mempolicy, kMpolDefault, nullptr, 0);
@@ -419,11 +442,11 @@ void probe_numa(adsb_ctx* c) {
   }
 }
 
-int ensure_pinned(adsb_ctx* c, void*& p, size_t& cap, size_t bytes) {
+int ensure_pinned(adsb_ctx* c, void*& p, size_t& cap, size_t bytes, bool coherent = false) {
   if (bytes <= cap) return 0;
   if (p) { HIPCHK(c, hipHostFree(p)); p = nullptr; cap = 0; }
   size_t want = bytes + bytes / 4 + 4096;
-  HIPCHK(c, host_alloc_near(c, &p, want));
+  HIPCHK(c, host_alloc_near(c, &p, want, coherent));
   cap = want;
   return 0;
 }
@@ -605,7 +628,7 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   // synchronisation at adsb_wait (the 48-byte summary travels the same way); bulk passes keep the DMA copy.
   const long long kDirectRecs = 16384;
   s.direct = s.tot <= kDirectRecs;
-  if (s.direct) { if ((r = ensure_pinned(c, s.h_out, s.h_out_cap, (size_t)s.tot * sizeof(Rec)))) return r; }
+  if (s.direct) { if ((r = ensure_pinned(c, s.h_out, s.h_out_cap, (size_t)s.tot * sizeof(Rec), true))) return r; }
   else if ((r = ensure(c, s.d_out, (size_t)s.tot * sizeof(Rec)))) return r;
   if ((r = ensure(c, s.d_seg, (size_t)(s.tot / kThreads + 2) * sizeof(int)))) return r;
   if ((r = ensure(c, s.d_blk_count, (size_t)nlists * sizeof(int)))) return r;
@@ -660,18 +683,23 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
     if (s.polled) {
       // a one-workgroup pass: its last store is the pass number (publish_small); spin on it -- bounded: a kernel that died
       // never stores it, and the stream synchronisation below reports why
+      // The spin is SHORT (the pass itself takes ~10 us; ~50 us covers a pass queued behind one or two others): a pass that
+      // sits behind more work than that -- a caller-owned stream, several submissions in flight -- is waited for by
+      // blocking on the stream instead of burning the calling thread's core (in GNU Radio: the framer's work() thread).
       const volatile int* seqp = &s.h_sum->pad_;
       const auto t0 = std::chrono::steady_clock::now();
       unsigned spins = 0;
       while (*seqp != s.seq) {
-        __builtin_ia32_pause();
-        if ((++spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        cpu_relax();
+        if ((++spins & 0x3Fu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(50)) break;
       }
       std::atomic_thread_fence(std::memory_order_acquire);
       if (*seqp != s.seq) {
         FINCHK(hipStreamSynchronize(c->stream));
         FINCHK(hipGetLastError());
+        std::atomic_thread_fence(std::memory_order_acquire);
         if (*seqp != s.seq) { s.busy = false; return fail(c, -EIO, "small pass finished without publishing its summary"); }
+        c->stats.poll_fallbacks++;
       }
     } else {
       FINCHK(hipEventSynchronize(s.done));
@@ -711,7 +739,7 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
     if (s.h_sum->long_count > s.args.long_cap) { s.busy = false; return fail(c, -EIO, "long-rise list overflow"); }
     *sum = *s.h_sum;
     const int nres = sum->n_kept;
-    int r = s.direct ? 0 : ensure_pinned(c, s.h_out, s.h_out_cap, (size_t)(nres > 0 ? nres : 1) * sizeof(Rec));
+    int r = s.direct ? 0 : ensure_pinned(c, s.h_out, s.h_out_cap, (size_t)(nres > 0 ? nres : 1) * sizeof(Rec), true);
     if (r) { s.busy = false; return r; }
     const Rec* recs_dev = (const Rec*)(s.direct ? s.h_out : s.d_out.p);
     if (nres > 0 && (!s.direct || (c->flags & ADSB_FLAG_CONFIDENCE))) {
@@ -796,7 +824,16 @@ int ensure_pool(adsb_ctx* c) {
   if (!c->pool) return fail(c, -ENOMEM, "copy pool");
   const unsigned hw = std::thread::hardware_concurrency();
   const int nt = c->copy_threads >= 0 ? c->copy_threads : (hw >= 16 ? 5 : (hw >= 4 ? 2 : 0));     // workers besides the caller
-  if (c->have_local_cpus && !(c->flags & ADSB_FLAG_NO_NUMA_BINDING)) { c->pool->cpus = c->local_cpus; c->pool->have_cpus = true; }
+  if (c->have_local_cpus && !(c->flags & ADSB_FLAG_NO_NUMA_BINDING)) {
+    // the GPU's local cpus, but never outside the mask the PROCESS was given (taskset, numactl --physcpubind, a cgroup):
+    // the workers run on the intersection, or stay unbound when that is empty
+    cpu_set_t mine, both;
+    CPU_ZERO(&mine);
+    if (sched_getaffinity(0, sizeof(mine), &mine) == 0) {
+      CPU_AND(&both, &mine, &c->local_cpus);
+      if (CPU_COUNT(&both) > 0) { c->pool->cpus = both; c->pool->have_cpus = true; }
+    }
+  }
   c->pool->start(nt);
   return 0;
 }
@@ -935,7 +972,7 @@ int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx
   for (hipEvent_t& e : c->ring_done)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { adsb_destroy(c); return -EIO; }
   for (Slot& sl : c->slot) {
-    if (host_alloc_near(c, (void**)&sl.h_sum, sizeof(Summary)) != hipSuccess) { adsb_destroy(c); return -ENOMEM; }
+    if (host_alloc_near(c, (void**)&sl.h_sum, sizeof(Summary), true) != hipSuccess) { adsb_destroy(c); return -ENOMEM; }
     memset(sl.h_sum, 0, sizeof(Summary));                        // (pad_ is the pass number finish() polls: starts at zero)
     if (hipEventCreate(&sl.ev0) != hipSuccess || hipEventCreate(&sl.ev1) != hipSuccess ||
         hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess ||

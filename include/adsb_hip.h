@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ADSB_ABI_VERSION 2
+#define ADSB_ABI_VERSION 3
 #define ADSB_MAX_SPS 100 /* highest sample rate accepted: 100 Msps (tested up to and including it against the reference) */
 #ifndef ADSB_MAX_IN_FLIGHT
 #define ADSB_MAX_IN_FLIGHT 3 /* adsb_submit_* calls that may be pending at once */
@@ -122,6 +122,8 @@ typedef struct adsb_stats {
   double detect_gap_ms;      /* sum of idle gaps on the compute stream between consecutive timed k_detect launches */
   uint64_t detect_gaps;      /* number of gaps summed */
   uint64_t longrun_pulses;   /* pulses longer than k_detect's LDS window, handled by the long-pulse kernel (sum over calls) */
+  uint64_t poll_fallbacks;   /* ABI 3: small passes whose pass number did not appear within the short spin and were waited for
+                              * by blocking on the stream instead (adsb_hip.hip: finish) */
 } adsb_stats;
 
 int adsb_abi_version(void);

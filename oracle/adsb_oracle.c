@@ -28,7 +28,9 @@ typedef struct {
 
 static const int TEMPLATE[16] = {1, 0, 1, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0}; /* framer.py:50 */
 
-/* np.median of w[0:n] in float32: odd -> middle, even -> f32(a+b)/2, NaN if n == 0 or any NaN */
+/* np.median of w[0:n] in float32: odd -> middle, even -> f32(a+b)/2, NaN if n == 0 or any NaN.  A median of zero is
+ * +0.0 whatever the signs of the zeros in the window: np.median takes np.mean of the middle element(s), whose sum starts
+ * from +0.0 (0.0 + -0.0 = +0.0) -- so -0.0 vs +0.0 never depends on how the partition ordered them. */
 static float median_f32(const float* w, int n) {
   float s[100];
   if (n <= 0) { union { uint32_t u; float f; } q; q.u = 0xFFC00000u; return q.f; }  /* np.median([]) = 0/0 */
@@ -39,9 +41,12 @@ static float median_f32(const float* w, int n) {
     while (j > 0 && s[j - 1] > v) { s[j] = s[j - 1]; --j; }
     s[j] = v;
   }
-  if (n & 1) return s[n / 2];
+  volatile float zero = 0.0f;
+  if (n & 1) { volatile float m = s[n / 2] + zero; return m; }
   volatile float sum = s[n / 2 - 1] + s[n / 2];
-  return sum / 2.0f;
+  volatile float h = sum / 2.0f;
+  volatile float m2 = h + zero;
+  return m2;
 }
 
 void oracle_mag2(const float* iq, int64_t n, float* out) {

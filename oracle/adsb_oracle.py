@@ -79,10 +79,12 @@ def _median_f32(w):
     if np.isnan(w).any():
         return np.float32(np.nan)          # a quiet NaN from the data propagates (0x7FC00000)
     s = np.sort(w)
+    # a median of zero is +0.0 whatever the signs of the zeros: np.median is np.mean of the middle element(s), and that
+    # sum starts from +0.0 (0.0 + -0.0 = +0.0) -- independent of how the partition ordered -0.0 and +0.0
     if n & 1:
-        return np.float32(s[n // 2])
+        return np.float32(np.float32(s[n // 2]) + np.float32(0.0))
     with np.errstate(all="ignore"):
-        return np.float32(np.float32(s[n // 2 - 1] + s[n // 2]) / np.float32(2.0))
+        return np.float32(np.float32(np.float32(s[n // 2 - 1] + s[n // 2]) / np.float32(2.0)) + np.float32(0.0))
 
 
 class FramerState:

@@ -31,13 +31,13 @@ def test_library_exports_every_declared_symbol(native):
     for n in names:
         assert hasattr(lib, n), "missing export " + n
     assert set(names) == set(native.EXPORTS)
-    assert lib.adsb_abi_version() == native.ABI_VERSION == 2
+    assert lib.adsb_abi_version() == native.ABI_VERSION == 3
 
 
 def test_struct_layouts(native):
     assert native.BURST_DTYPE.itemsize == 32
     assert native.BURST_DTYPE.fields["bits"][1] == 16 and native.BURST_DTYPE.fields["flags"][1] == 30
-    assert ctypes.sizeof(native.Stats) == 96
+    assert ctypes.sizeof(native.Stats) == 104          # ABI 3: + poll_fallbacks
 
 
 def test_no_cpu_fallback_without_device(native):

@@ -1193,3 +1193,37 @@ def test_c_abi_output_array_and_error_paths(native):
     assert lib.adsb_wait(ctx._h, 7, None, 0, ctypes.byref(n_out)) == -22
     # empty input is a valid call
     assert lib.adsb_process_iq(ctx._h, ctypes.c_void_p(g.iq.ctypes.data), 0, 0, None, 0, ctypes.byref(n_out)) == 0 and n_out.value == 0
+
+
+def test_polled_small_passes_never_show_stale_or_partial_records(native):
+    """Scheduler-sized framer calls signal completion through memory: the kernel's last store is the pass number the host
+    polls (publish_small: every thread fences its record stores to system scope in front of the workgroup barrier, then
+    thread 0 publishes).  Hammer such calls, alternating between chunks with DIFFERENT bursts, with FRAMER_SLICES so that
+    the records carry bits written by several wavefronts, and compare every call's records -- read the moment the poll
+    returns -- byte for byte with the chunk's verified records (equal to the C oracle's for the same samples): a record
+    that is stale (the previous call's) or partial (a half not yet arrived) would differ."""
+    from gr_adsb_amd import modulator as M
+    from oracle import c_oracle as C
+    sps, H = 2, 16
+    chunks, want = [], []
+    ref = native.Context(2e6, 0.01, flags=native.FLAG_FRAMER_SLICES)
+    for seed in range(6):
+        x = M.mag2(M.synth_iq(6000, 2e6, 30000 + 7000 * seed, seed=900 + seed))
+        in0 = np.concatenate([np.zeros(H - 1, np.float32), x])
+        ref.reset()
+        w = ref.framer_work(in0, len(x), 0).copy()
+        assert len(w) >= 2
+        assert_recs_equal(w, C.canonical(x, sps, np.float32(0.01)), "small pass vs the C oracle")
+        chunks.append(in0)
+        want.append(w.tobytes())
+    assert len(set(want)) == len(want)
+    ref.close()
+    ctx = native.Context(2e6, 0.01, flags=native.FLAG_FRAMER_SLICES)
+    for k in range(6000):
+        i = (k * 5 + k // 7) % len(chunks)
+        ctx.reset()
+        got = ctx.framer_work(chunks[i], len(chunks[i]) - (H - 1), 0)
+        assert got.tobytes() == want[i], "call %d (chunk %d): records differ from the blocking pass" % (k, i)
+    st = ctx.stats()
+    assert st["poll_fallbacks"] <= 60, st          # the short spin catches (nearly) every such call on an idle GPU
+    ctx.close()

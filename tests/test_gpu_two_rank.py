@@ -108,7 +108,7 @@ def test_bench_eight_ranks_one_gpu_all_seven_seams():
     env = dict(os.environ, ADSB_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1",
-           "--log2n", "22", "--fs", "20e6", "--bursts", "3000", "--min-time", "0.02"]
+           "--log2n", "22", "--fs", "20e6", "--bursts", "3000", "--min-time", "0.02", "--no-config4"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -120,12 +120,45 @@ def test_bench_eight_ranks_one_gpu_all_seven_seams():
     assert [r_["rank"] for r_ in mg["per_rank"]] == list(range(8))
 
 
+def test_bench_plain_launch_starts_its_own_ranks_and_carries_config4():
+    """`python bench.py --gpus 2` with NO launcher around it: the bench starts its two ranks itself (never a line that says
+    n_gpus: 1) and, with N > 1, the line carries BASELINE config 4 -- one 20 Msps stream tiled as N overlapped shards -- as a
+    weak and a strong scaling leg, each with per-rank roofline figures and a seam check.  Both ranks on cuda:0."""
+    env = dict(os.environ, ADSB_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--log2n", "23",
+           "--min-time", "0.05", "--extra-steps", "4", "--extra-min-time", "0.05", "--no-host-fed-multi"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["launched_by"].startswith("bench.py itself")
+    assert d["config"]["seams_identical"] is True and d["config"]["rank_sync"] == "gloo"
+    c4 = d["config4_20msps"]
+    assert c4["fs"] == 20e6 and c4["rank_sync"] == "gloo"
+    for leg, n_own in (("weak", 1 << 23), ("strong", 1 << 22)):
+        L = c4[leg]
+        assert L["scaling"] == leg and L["samples_per_gpu_per_step"] == n_own and L["stream_samples_per_step"] == 2 * n_own
+        assert L["value"] > 0 and L["seam_check"]["all_identical"] and L["seam_check"]["per_seam"][0]["bursts_compared"] > 20
+        assert [r_["rank"] for r_ in L["per_rank"]] == [0, 1]
+        assert all(0.0 < r_["roofline_frac"] < 1.0 and r_["kernel_ms"] > 0 for r_ in L["per_rank"])
+        assert d["config"]["cfg4_%s_seams_identical" % leg] is True and d["config"]["cfg4_%s_msps" % leg] == L["value"]
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """Under a launcher whose world size is not --gpus the bench exits non-zero instead of printing a line for the wrong N."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 2 and "WORLD_SIZE=1 but --gpus 2" in r.stderr and not r.stdout.strip()
+
+
 def test_bench_two_ranks_one_gpu_seam_check():
-    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run), both ranks on cuda:0."""
+    """bench.py --gpus 2 under an external launcher (torch.distributed.run), both ranks on cuda:0."""
     env = dict(os.environ, ADSB_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--log2n", "23", "--min-time", "0.05"]
+           "--log2n", "23", "--min-time", "0.05", "--no-config4"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -147,7 +180,7 @@ def test_bench_force_dist_initialises_like_a_multi_gpu_launch(world):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("ADSB_BENCH_ONE_GPU", None)
     tail = ["--gpus", str(world), "--force-dist", "--steps", "4", "--warmup", "1", "--log2n", "23", "--min-time", "0.05",
-            "--no-cpu", "--no-extra", "--no-hostfed", "--no-host-fed-multi"]
+            "--no-cpu", "--no-extra", "--no-hostfed", "--no-host-fed-multi", "--no-config4"]
     port = str(_free_port())
     if world == 1:
         env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)

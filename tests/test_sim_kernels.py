@@ -536,3 +536,29 @@ def test_output_stage_flushes_in_the_middle_of_a_chunk(fs, bps, n):
     got, so = simlib.sim_canonical(1, x, fs, 0.01, grid_max=1)
     assert so.overflow == 0 and so.n_rec > 40 * 4
     assert_recs_equal(got, want, "stage")
+
+
+@pytest.mark.parametrize("name", ["Pnegzero_2msps", "Pnegzero_8msps"])
+def test_signed_zeros_in_the_noise_window_match_the_reference(name):
+    """tests/golden/Pnegzero_*.npz (tools/make_golden_negzero.py, the REAL reference's outputs): -0.0 and +0.0 mixed in the
+    noise window, zero medians in most windows.  np.median is np.mean of the middle element(s) and that sum starts from
+    +0.0, so a zero median is always +0.0 (SNR +inf, never NaN): the emulated device code must agree bit for bit, in one
+    call and work() call by work() call (chunk starts cut the window to every odd and even length)."""
+    g = Golden(name)
+    assert int((g.x.view(np.uint32) == 0x80000000).sum()) > 1000
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        recs, so = simlib.sim_canonical(1, g.x, g.fs, g.thr)
+        assert_recs_match_golden(recs, g)
+        assert not np.any(recs["median"].view(np.uint32) == 0x80000000), "a zero median is +0.0 (framer.py:157: np.median)"
+        assert int(np.isposinf(np.float32(10.0) * np.log10(recs["peak"] / recs["median"])).sum()) >= 40
+        H = 8 * g.sps
+        buf = np.concatenate([np.zeros(H - 1, np.float32), g.x])
+        fr = simlib.SimFramer(g.fs, g.thr)
+        pos, outs = 0, []
+        for N in g.sched("random"):
+            outs.append(fr.work(buf[pos:pos + N + H - 1], N, pos)[0])
+            pos += N
+        recs = np.concatenate(outs)
+        assert np.array_equal(recs["offset"], g.get("random", "tag_offsets"))
+        assert np.array_equal(snr_bits(recs["peak"], recs["median"]), g.get("random", "tag_snr_bits"))

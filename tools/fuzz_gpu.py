@@ -1,5 +1,7 @@
-"""GPU fuzz campaign (not part of the test suite): adversarial streams through the C ABI vs the C oracle for a given
-number of seconds, float |IQ|^2 and complex64 entry points, canonical and sharded.  python tools/fuzz_gpu.py [seconds] [seed0]"""
+"""GPU fuzz campaign: adversarial streams through the C ABI vs the C oracle for a given number of seconds -- float |IQ|^2,
+complex64 and integer entry points, canonical, block-by-block, host-fed, GNU Radio chunk schedules (paired and unpaired
+blocks), confidence ratios, the length-aware gate, rates 2-100 Msps.  python tools/fuzz_gpu.py [seconds] [seed0]
+A bounded run with fixed seeds is part of `-m gpu` (tests/test_gpu_fuzz.py): run(budget, seed0)."""
 import os
 import sys
 import time
@@ -20,6 +22,13 @@ from test_sim_property import adversarial_stream  # noqa: E402
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    print("fuzz: %(cases)d cases (%(gr)d with a GNU Radio chunk schedule), %(bursts)d bursts, seeds up to %(last_seed)d, %(seconds).0f s: "
+          "all identical" % run(budget, seed))
+
+
+def run(budget, seed, max_n=None):
+    """Cases with seeds seed, seed + 1, ... until `budget` seconds are used; raises AssertionError on the first difference.
+    max_n: leave out stream lengths above it (the bounded test run skips the multi-megasample cases)."""
     _native.load()
     ctxs = {}
     la_ctxs = {}
@@ -32,9 +41,14 @@ def main():
     while time.time() - t0 < budget:
         rng = np.random.default_rng(seed)
         n = int(rng.choice(sizes, p=np.array([3] * 20 + [2, 1, 0.5, 0.25]) / (60 + 3.75)))
+        if max_n is not None and n > max_n:
+            n = int(max_n)
         sps = int(rng.choice([2, 4, 8, 20, 6, 10, 12, 16, 30, 100]))      # instantiated rates + run-time-stride ones
         thr = float(rng.choice([0.01, 0.0099, 0.0101, 0.004, 0.05]))
         x = adversarial_stream(rng, n, sps)
+        if rng.random() < 0.2:                        # signed zeros in the noise windows (a zero median is +0.0: np.mean's sum)
+            z = np.flatnonzero(x == 0)
+            x[z[rng.random(len(z)) < 0.5]] = np.float32(-0.0)
         ctx = ctxs.setdefault(sps, _native.Context(sps * 1e6, thr))
         ctx.set_threshold(thr)
         what = "seed %d n %d sps %d thr %g" % (seed, n, sps, thr)
@@ -113,7 +127,9 @@ def main():
             else:
                 ob = fmt == _native.FMT_CU8
                 q = M.quantize_iq8(iqf, full_scale=2.0, offset_binary=ob)
-                scale = float(np.float32(2.0 / 255.0 if ob else 2.0 / 127.0))
+                # int8: half of the cases with a power-of-two scale (the dot-product instance of k_detect), half with 2/127
+                # (the generic int8 instance)
+                scale = float(np.float32(2.0 / 255.0 if ob else (2.0 / 128.0 if rng.random() < 0.5 else 2.0 / 127.0)))
                 xq = O.mag2_iq8(q, scale, ob)
             ctx.set_format_scale(fmt, scale)
             assert_recs_equal(ctx.process_format(fmt, q), C.canonical(xq, sps, np.float32(thr)), what + " fmt %d" % fmt)
@@ -145,7 +161,10 @@ def main():
         n_cases += 1
         n_bursts += len(want)
         seed += 1
-    print("fuzz: %d cases (%d with a GNU Radio chunk schedule), %d bursts, seeds up to %d, %.0f s: all identical" % (n_cases, n_gr[0], n_bursts, seed - 1, time.time() - t0))
+    for group in (ctxs, la_ctxs, cf_ctxs):
+        for c_ in group.values():
+            c_.close()
+    return {"cases": n_cases, "gr": n_gr[0], "bursts": n_bursts, "last_seed": seed - 1, "seconds": time.time() - t0}
 
 
 if __name__ == "__main__":

@@ -1208,7 +1208,7 @@ def test_polled_small_passes_never_show_stale_or_partial_records(native):
     chunks, want = [], []
     ref = native.Context(2e6, 0.01, flags=native.FLAG_FRAMER_SLICES)
     for seed in range(6):
-        x = M.mag2(M.synth_iq(6000, 2e6, 30000 + 7000 * seed, seed=900 + seed))
+        x = M.mag2(M.synth_iq(6000, 2e6, 3000 + 1000 * seed, seed=900 + seed))      # ~9-24 bursts, some overlapping
         in0 = np.concatenate([np.zeros(H - 1, np.float32), x])
         ref.reset()
         w = ref.framer_work(in0, len(x), 0).copy()

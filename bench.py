@@ -214,47 +214,15 @@ def isolated_kernel_ms(fe, fmt, iq, n, launches=8):
 def sharded_on_one_gpu(fe, iq, n, sps, shards, depth):
     """BASELINE config 4's decomposition on ONE GPU: the resident stream as `shards` overlapped time shards, each
     detected and gated on the device as a fresh stream, heads re-gated on the host with the carried end-of-burst
-    state (the multi-GPU stitch run sequentially).  Returns (records of the whole stream, callable running one step)."""
-    from gr_adsb_amd import _native, replay
-    from gr_adsb_amd.frontend import shard_plan
-    plans = [p for p in shard_plan(n, shards, sps) if p["own_hi"] > p["own_lo"]]
+    state (the multi-GPU stitch run sequentially).  Since round 5 the whole loop -- plan, submit three deep, wait, fix-up,
+    fallback -- is ONE C call (adsb_process_sharded_device): the Python loop it replaces cost ~28 us per shard on top of the
+    52 us a 2^25-sample pass takes (tools/pass_cost.py).  Returns a callable running one step -> the stream's records."""
+    from gr_adsb_amd import _native
+    out = np.empty(max(1 << 16, n // 2048), dtype=_native.BURST_DTYPE)
 
     def one_step(collect):
-        eob, pending, out = _native.EOB_NONE, [], []
-
-        def finish(p, t):
-            nonlocal eob
-            recs = fe.wait(t, copy=False)
-            kept = _native.shard_fixup(recs, sps, eob, inplace=True)
-            if kept is None:                              # head region ends inside a chain: ungated list + greedy gate
-                stash = [(q, fe.wait(u)) for q, u in pending]
-                pending.clear()
-                kept = replay.greedy_gate(fe.shard_tensor(iq[p["lo"]:p["hi"]], p["lo"], p["own_lo"], p["own_hi"], n), sps, eob)
-                if len(kept):
-                    eob = int(kept["offset"][-1]) + int(_native.gate_window(kept[-1:], sps)[0])
-                if collect:
-                    out.append(kept.copy())
-                for q, r in stash:
-                    k2 = _native.shard_fixup(r, sps, eob)
-                    assert k2 is not None, "bench: consecutive unsynchronised shards"
-                    if len(k2):
-                        eob = int(k2["offset"][-1]) + int(_native.gate_window(k2[-1:], sps)[0])
-                    if collect:
-                        out.append(k2)
-                return
-            if len(kept):
-                eob = int(kept["offset"][-1]) + int(_native.gate_window(kept[-1:], sps)[0])
-            if collect:
-                out.append(kept.copy())
-
-        for p in plans:
-            pending.append((p, fe.submit_shard_tensor(iq[p["lo"]:p["hi"]], p["lo"], p["own_lo"], p["own_hi"], n,
-                                                      head_cands=64)))
-            if len(pending) == depth:
-                finish(*pending.pop(0))
-        while pending:
-            finish(*pending.pop(0))
-        return np.concatenate(out) if collect and out else None
+        recs = fe.process_sharded_tensor(_native.FMT_FC32, iq, shards, out=out)
+        return recs.copy() if collect else None
 
     return one_step
 
@@ -290,7 +258,9 @@ def extra_configs(args, dev, depth):
                "steps": args.extra_steps, "repeats": len(times), "bursts_per_step": int(nb),
                "longrun_calls": int(st["longrun_calls"]), "retries": int(st["retries"]),
                "long_pulses_per_step": round(st["longrun_pulses"] / max(1, st["calls"]), 2),
-               "roofline": roofline_of(st, "fc32", iso_ms)}
+               "roofline": roofline_of(st, "fc32", iso_ms),
+               "product_default": untimed_context_ms(args, dev.index, _native.FMT_FC32, iq, n, depth, torch.cuda.synchronize, fs=fs,
+                                                     steps=args.extra_steps)}
         tr, tr_src = pmc_traffic("fc32", fs, sp["bursts"], bool(sp["synth"]), log2n)
         rec["roofline"]["traffic"] = tr
         rec["roofline"]["traffic_source"] = tr_src or "none for this workload (see profiles/)"
@@ -304,6 +274,9 @@ def extra_configs(args, dev, depth):
                             "sample": "first 2^26 samples vs oracle/adsb_oracle.c"}
         rec["cpu_c_port_msamples_per_s"] = round(cpu_n / tc / 1e6, 1)
         if sp.get("shards"):
+            # (a context of the product's default kind: no ADSB_FLAG_TIMING, the shards' passes free to overlap -- this leg
+            # quotes a wall time, not a kernel duration)
+            fe_t, fe = fe, FrontEnd(fs, args.threshold, device=dev.index, timing=False)
             whole = fe.process_iq_tensor(iq, 0)
             one_step = sharded_on_one_gpu(fe, iq, n, sps, sp["shards"], depth)
             stitched = one_step(True)
@@ -320,10 +293,13 @@ def extra_configs(args, dev, depth):
             msh = float(np.median(tt)) * 1e3
             rec["sharded"] = {"shards": sp["shards"], "value": round(n / msh / 1e3, 1), "unit": "Msamples/s",
                               "ms_per_step": round(msh, 4),
-                              "note": "one step = all %d shards submitted %d deep + host fix-up of every head" % (sp["shards"], depth),
+                              "note": "one step = adsb_process_sharded_device: all %d shards submitted %d deep + host fix-up of every head, in C" % (sp["shards"], depth),
+                              "shard_fallbacks": int(fe.stats()["shard_fallbacks"]),
                               "stitched_equals_single_call": recs_match(stitched, whole) and bool(
                                   np.array_equal(stitched["flags"] & 0x1FE1, whole["flags"] & 0x1FE1)),
                               "bursts": int(len(whole))}
+            fe.ctx.close()
+            fe = fe_t
         out.append(rec)
         del iq, fe
         torch.cuda.empty_cache()
@@ -361,7 +337,9 @@ def format_legs(args, dev, depth):
                     "sc8g": "int8 IQ (scale 4/127: generic int8 instance)", "cu8": "uint8 offset-binary IQ"}[name], log2n),
                "kernel_instance": {"sc8": "k_detect<int8, power-of-two scale>", "sc8g": "k_detect<int8, any scale>"}.get(name, "k_detect<%s>" % name),
                "value": round(n / ms / 1e3, 1), "unit": "Msamples/s", "ms_per_step": round(ms, 4), "bursts_per_step": int(nb),
-               "roofline": roofline_of(st, name, iso_ms)}
+               "roofline": roofline_of(st, name, iso_ms),
+               "product_default": untimed_context_ms(args, dev.index, fmt, q, n, depth, torch.cuda.synchronize, fs=fs, scale=scale,
+                                                     steps=args.extra_steps)}
         tr, tr_src = pmc_traffic("sc8" if name == "sc8g" else name, fs, 1000.0, False, log2n)
         rec["roofline"]["traffic"] = tr
         rec["roofline"]["traffic_source"] = tr_src or "none for this workload (see profiles/)"
@@ -1007,6 +985,8 @@ def main():
             key = rec["name"].split("_")[0].replace("config", "cfg") if rec["name"].startswith("config") else rec["format"]
             cfgd[key + "_frac"] = rec["roofline"]["frac"]
             cfgd[key + "_ms"] = rec["ms_per_step"]
+            if "product_default" in rec:
+                cfgd[key + "_ms_untimed_ctx"] = rec["product_default"]["ms_per_step"]
             cfgd[key + "_identical"] = bool(rec["bit_match"]["identical"])
             if "sharded" in rec:
                 cfgd[key + "_8shards_msps"] = rec["sharded"]["value"]
@@ -1037,16 +1017,21 @@ def main():
     return result
 
 
-def untimed_context_ms(args, device, fmt, iq, n, depth, sync_all, repeats=3):
-    """The headline pipeline on a context created WITHOUT ADSB_FLAG_TIMING -- the product default: no HIP event pair between
-    consecutive k_detect launches.  Same buffer, same depth, `steps` steps per repeat, median of a few repeats."""
+def untimed_context_ms(args, device, fmt, iq, n, depth, sync_all, repeats=3, fs=None, scale=None, steps=None):
+    """The same pipeline on a context created WITHOUT ADSB_FLAG_TIMING -- the product default.  Two differences from the timed
+    context every roofline figure comes from: no HIP event pair around k_detect, and (round 5) a schedule of its own -- a timed
+    context keeps its k_detect launches one behind the other so that each event pair brackets ONE launch with the machine to
+    itself; the default lets consecutive passes overlap on one stream per pipeline slot (passes over more than 4 GiB of input
+    excepted: gr_adsb_amd/csrc/adsb_hip.hip, enqueue).  Same buffer, same depth, `steps` steps per repeat, median of a few."""
+    from gr_adsb_amd import _native
     from gr_adsb_amd.frontend import FrontEnd
-    fe2 = FrontEnd(args.fs, args.threshold, device=device, timing=False,
-                   flags=0)
+    fs = args.fs if fs is None else fs
+    steps = args.steps if steps is None else steps
+    fe2 = FrontEnd(fs, args.threshold, device=device, timing=False, flags=0)
     if fmt not in (0, 1):
         # the integer wire formats convert with the scale the timed context was given (quantise_for)
-        from gr_adsb_amd import _native
-        fe2.ctx.set_format_scale(fmt, {_native.FMT_SC16: 4.0 / 32767.0, _native.FMT_SC8: 4.0 / 128.0, _native.FMT_CU8: 4.0 / 255.0}[fmt])
+        fe2.ctx.set_format_scale(fmt, scale if scale is not None else
+                                 {_native.FMT_SC16: 4.0 / 32767.0, _native.FMT_SC8: 4.0 / 128.0, _native.FMT_CU8: 4.0 / 255.0}[fmt])
     pend = []
     for _ in range(3):
         fe2.ctx.process_format_device(fmt, iq.data_ptr(), n, 0, fetch=False)
@@ -1054,18 +1039,19 @@ def untimed_context_ms(args, device, fmt, iq, n, depth, sync_all, repeats=3):
     for _ in range(repeats):
         sync_all()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             pend.append(fe2.submit_format_tensor(fmt, iq, 0))
             if len(pend) == depth:
                 nb = fe2.wait(pend.pop(0), fetch=False)
         while pend:
             nb = fe2.wait(pend.pop(0), fetch=False)
         sync_all()
-        tt.append((time.perf_counter() - t0) / args.steps * 1e3)
+        tt.append((time.perf_counter() - t0) / steps * 1e3)
     fe2.ctx.close()
-    return {"ms_per_step": round(float(np.median(tt)), 4), "repeats": repeats, "steps_per_repeat": args.steps,
+    return {"ms_per_step": round(float(np.median(tt)), 4), "repeats": repeats, "steps_per_repeat": steps,
             "bursts_per_step": int(nb), "msamples_per_s": round(n / float(np.median(tt)) / 1e3, 1),
-            "note": "same buffer and depth on a context without ADSB_FLAG_TIMING (no event pair between k_detect launches)"}
+            "note": "same buffer and depth on a context without ADSB_FLAG_TIMING: no event pair around k_detect, consecutive "
+                    "passes free to overlap (one stream per pipeline slot) unless a pass reads more than 4 GiB"}
 
 
 def seam_check(args, fe, dev, rank, n_gpus, sps, n_own, stream_len, kept, ag_obj, fs=None, bursts=None, seed=None, synth=None):

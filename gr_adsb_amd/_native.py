@@ -4,6 +4,7 @@ The product path: there is NO CPU implementation behind this module.  If the sha
 missing, or no HIP device can be opened, the import / constructor raises -- it never falls back.
 """
 import ctypes
+import errno
 import os
 
 import numpy as np
@@ -21,7 +22,7 @@ FLAG_SINGLE_STREAM = 8    # profiling aid: the sparse tail of a pass on the comp
 FLAG_FRAMER_SLICES = 32   # adsb_framer_work also returns the 112 bits of tags whose burst ends inside the call's input
 FLAG_NO_NUMA_BINDING = 64 # host side not placed on the GPU's NUMA node (default: page-locked buffers and copy threads are)
 FLAG_LOW_LATENCY = 16     # the tail of a pass runs beside the next pass's k_detect: results a pass earlier, 1-2 % less throughput
-ABI_VERSION = 3
+ABI_VERSION = 4
 # input sample formats (include/adsb_hip.h ADSB_FMT_*): numpy dtype of the flat host array, items per sample
 FMT_FC32, FMT_MAG2, FMT_SC16, FMT_SC8, FMT_CU8 = 0, 1, 2, 3, 4
 FMT_LAYOUT = {FMT_FC32: (np.complex64, 1), FMT_MAG2: (np.float32, 1), FMT_SC16: (np.int16, 2), FMT_SC8: (np.int8, 2),
@@ -43,7 +44,7 @@ EXPORTS = [
     "adsb_set_iq16_scale", "adsb_process_iq16", "adsb_process_iq16_device",
     "adsb_set_format_scale", "adsb_process_format", "adsb_process_format_device", "adsb_submit_format_device",
     "adsb_submit_format_host", "adsb_last_confidence",
-    "adsb_framer_work", "adsb_demod_work", "adsb_shard_device", "adsb_shard_host", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_mode_s_syndrome", "adsb_plan_chunks", "adsb_get_stats",
+    "adsb_framer_work", "adsb_demod_work", "adsb_shard_bounds", "adsb_process_sharded_device", "adsb_shard_device", "adsb_shard_host", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_mode_s_syndrome", "adsb_plan_chunks", "adsb_get_stats",
     "adsb_reset_stats", "adsb_detect_history", "adsb_numa_info", "adsb_host_alloc_near", "adsb_last_error", "adsb_host_alloc", "adsb_host_free", "adsb_host_register", "adsb_host_unregister",
 ]
 
@@ -53,7 +54,7 @@ class Stats(ctypes.Structure):
                 ("detect_bytes", ctypes.c_uint64), ("calls", ctypes.c_uint64), ("retries", ctypes.c_uint64),
                 ("longrun_calls", ctypes.c_uint64), ("detect_grid", ctypes.c_uint64), ("blocks_per_cu", ctypes.c_uint64),
                 ("detect_gap_ms", ctypes.c_double), ("detect_gaps", ctypes.c_uint64), ("longrun_pulses", ctypes.c_uint64),
-                ("poll_fallbacks", ctypes.c_uint64)]
+                ("poll_fallbacks", ctypes.c_uint64), ("shard_fallbacks", ctypes.c_uint64)]
 
 
 class AdsbError(RuntimeError):
@@ -118,6 +119,9 @@ def load():
     lib.adsb_shard_device.argtypes = [vp, c.c_int, vp, i64, i64, i64, i64, i64, i32, vp, i32, c.POINTER(i32)]
     lib.adsb_shard_host.argtypes = [vp, c.c_int, vp, i64, i64, i64, i64, i64, i32, c.c_uint32, vp, i32, c.POINTER(i32)]
     lib.adsb_shard_fixup.argtypes = [vp, i32, c.c_int, i64, c.POINTER(i32)]
+    lib.adsb_shard_bounds.argtypes = [i64, i32, i32, c.c_int, i64, c.POINTER(i64), c.POINTER(i64), c.POINTER(i64), c.POINTER(i64)]
+    lib.adsb_shard_bounds.restype = c.c_int32
+    lib.adsb_process_sharded_device.argtypes = [vp, c.c_int, vp, i64, i64, i32, vp, i32, c.POINTER(i32)]
     lib.adsb_stitch.argtypes = [vp, i32, c.c_int, c.POINTER(i32)]
     lib.adsb_snr_db.argtypes = [f32, f32]
     lib.adsb_snr_db.restype = f32
@@ -360,6 +364,22 @@ class Context:
         self.last_demod_flags = ok        # ok[t] = BURST_DEMOD | parity pre-filter bits (0 = dropped)
         return bits, ok.astype(bool), ratio
 
+    def process_sharded_device(self, fmt, dev_ptr, n, shards, abs_offset=0, out=None):
+        """The resident stream as `shards` overlapped time shards, pipelined and stitched inside the library (one C call:
+        adsb_process_sharded_device); bit-identical to process_format_device over the whole buffer.  out: a BURST_DTYPE array
+        to receive the records (reused by callers that repeat the call); grown and retried when too small."""
+        if out is None:
+            out = np.empty(max(4096, int(n) // 4096), dtype=BURST_DTYPE)
+        while True:
+            n_out = ctypes.c_int32(0)
+            rc = self.lib.adsb_process_sharded_device(self._h, int(fmt), ctypes.c_void_p(int(dev_ptr)), int(n), int(abs_offset),
+                                                      int(shards), out.ctypes.data_as(ctypes.c_void_p), len(out), ctypes.byref(n_out))
+            if rc == -errno.ENOSPC and n_out.value > len(out):
+                out = np.empty(n_out.value + n_out.value // 8 + 16, dtype=BURST_DTYPE)
+                continue
+            self._chk(rc)
+            return out[:n_out.value]
+
     def shard_device(self, fmt, dev_ptr, n, origin, own_lo, own_hi, stream_len, head_cands=0):
         n_out = ctypes.c_int32(0)
         self._chk(self.lib.adsb_shard_device(self._h, int(fmt), ctypes.c_void_p(int(dev_ptr)), int(n), int(origin), int(own_lo),
@@ -545,6 +565,15 @@ def burst_df(recs):
 def parity_ok(recs):
     """True where the decoder's check_parity() will pass without an aircraft table (DF 11/17/18/19, syndrome 0)."""
     return (recs["flags"] & BURST_PARITY_OK) != 0
+
+
+def shard_bounds(stream_len, n_shards, g, sps, align=4096):
+    """adsb_shard_bounds: (own_lo, own_hi, lo, hi) of shard g (pure host arithmetic, no device needed)."""
+    v = [ctypes.c_int64(0) for _ in range(4)]
+    rc = load().adsb_shard_bounds(int(stream_len), int(n_shards), int(g), int(sps), int(align), *[ctypes.byref(x) for x in v])
+    if rc:
+        raise AdsbError(rc, "adsb_shard_bounds")
+    return tuple(x.value for x in v)
 
 
 def plan_chunks(n_samples, resident_wavefronts):

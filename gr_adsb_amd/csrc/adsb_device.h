@@ -677,11 +677,15 @@ __device__ __forceinline__ void stage_flush(Stage& st, int upto, int lane) {
     const int room = st.cap - st.base;                         // (a list that is not a multiple of 16 long: never past its end)
     const int nr = ((cnt + 3) & ~3) < room ? ((cnt + 3) & ~3) : room;
     const int nc = kStage < room ? kStage : room;
+    // NON-TEMPORAL stores (round 5): the lines are written once and read once, much later, by the tail -- written through
+    // instead of sitting dirty in the L2 until the read stream evicts them.  Measured on one box, same process layout
+    // (profiles/r05_slot_variants_nt_arena.txt): k_detect 1.283-1.288 -> 1.270-1.279 ms per 2^30 samples, and in a process
+    // whose output buffers had landed badly (two of three slots at 1.332) 1.308.
     if (lane < 2 * nr) {
-      const RecHalf v = reinterpret_cast<const RecHalf*>(st.buf->rec)[lane];
-      reinterpret_cast<RecHalf*>(st.recs + st.base)[lane] = v;
+      const adsb_u64x2 v = reinterpret_cast<const adsb_u64x2*>(st.buf->rec)[lane];
+      adsb_st_stream(reinterpret_cast<adsb_u64x2*>(st.recs + st.base) + lane, v);
     }
-    if (lane < nc) st.cands[st.base + lane] = st.buf->cand[lane];
+    if (lane < nc) adsb_st_stream(st.cands + st.base + lane, st.buf->cand[lane]);
     adsb_wave_sync();                                        // ... and these reads in front of the stage's next use
     st.base = upto;
   }
@@ -1643,10 +1647,12 @@ __global__ void __launch_bounds__(kThreads) k_count(const unsigned long long* so
 // k_compact also does what a separate single-workgroup scan kernel used to: every workgroup sums the segment counts
 // in front of its segment itself (a few hundred ints, L2 resident) -- one launch fewer on the tail of every pass.
 // Emits the survivors' burst records (built by k_detect / k_longrun, ordered by k_gather) with kKept / kHead added.
+template <bool HOSTCOPY = false>
 __device__ __forceinline__ void compact_body(int bid, int nb, const unsigned long long* sorted, const Rec* recs, const unsigned* sorted_src,
                                              Summary* sum, const int* seg_count, unsigned fmask, unsigned fwant, int head_n,
                                              Rec* out, int out_cap, int* long_count, unsigned long long* long_lastp,
-                                             OrderAcc* acc = nullptr, Summary* host_sum = nullptr) {
+                                             OrderAcc* acc = nullptr, Summary* host_sum = nullptr, Rec* host_out = nullptr,
+                                             int host_cap = 0) {
   __shared__ int s_c[kWaves];
   __shared__ int s_pre[kWaves], s_tot[kWaves];
   const int n = sum->n_rec;
@@ -1720,11 +1726,24 @@ __device__ __forceinline__ void compact_body(int bid, int nb, const unsigned lon
     off += lanes_below(m, lane);
     if (seg == 0 && threadIdx.x == 0 && !host_sum) sum->n_kept = total;
     if (k && off < out_cap) {
-      Rec r = recs[sorted_src[i]];
+      // (the record as two 16-byte VECTOR values: as an aggregate -- one Rec or two RecHalf -- with a second store behind the
+      // parity loop the compiler parked half of it in 4 KB of LDS, which no longer fits beside five k_detect workgroups:
+      // tests/test_abi.py)
+      typedef unsigned long long u64x2 __attribute__((vector_size(16)));      // (clang and g++: the emulator build)
+      const u64x2* src = reinterpret_cast<const u64x2*>(recs + sorted_src[i]);
+      const u64x2 h0 = src[0];
+      u64x2 h1 = src[1];
       unsigned fl = cand_flags(c) & (kKept | kHead);
-      if ((unsigned)(r.w[3] >> 48) & kDemod) fl |= parity_flags_of(r.w[2], r.w[3]);
-      r.w[3] |= (unsigned long long)fl << 48;
-      out[off] = r;
+      if ((unsigned)(h1[1] >> 48) & kDemod) fl |= parity_flags_of(h1[0], h1[1]);
+      h1[1] |= (unsigned long long)fl << 48;
+      u64x2* dst = reinterpret_cast<u64x2*>(out + off);
+      dst[0] = h0; dst[1] = h1;
+      // mid-size pass: the first host_cap records ALSO go straight into the pinned result buffer (adsb_hip.hip: enqueue) --
+      // when the pass delivers no more than that, adsb_wait has them without a copy of its own
+      if (HOSTCOPY && off < host_cap) {
+        u64x2* hd = reinterpret_cast<u64x2*>(host_out + off);
+        hd[0] = h0; hd[1] = h1;
+      }
       if (off == total - 1 && !host_sum) sum->last_kept_p = cand_p(c);
     }
     __syncthreads();
@@ -1733,9 +1752,10 @@ __device__ __forceinline__ void compact_body(int bid, int nb, const unsigned lon
 __global__ void __launch_bounds__(kThreads) k_compact(const unsigned long long* sorted, const Rec* recs, const unsigned* sorted_src, Summary* sum,
                                                       const int* seg_count, unsigned fmask, unsigned fwant, int head_n,
                                                       Rec* out, int out_cap, int* long_count,
-                                                      unsigned long long* long_lastp, OrderAcc* acc, Summary* host_sum) {
-  compact_body((int)blockIdx.x, (int)gridDim.x, sorted, recs, sorted_src, sum, seg_count, fmask, fwant, head_n, out, out_cap,
-               long_count, long_lastp, acc, host_sum);
+                                                      unsigned long long* long_lastp, OrderAcc* acc, Summary* host_sum,
+                                                      Rec* host_out, int host_cap) {
+  compact_body<true>((int)blockIdx.x, (int)gridDim.x, sorted, recs, sorted_src, sum, seg_count, fmask, fwant, head_n, out, out_cap,
+                     long_count, long_lastp, acc, host_sum, host_out, host_cap);
 }
 
 // ---- k_tail_small: the whole tail of a SMALL pass (a GNU Radio work() call: a few lists, a few hundred centres at most)

@@ -53,6 +53,10 @@ __device__ __forceinline__ Q adsb_ld_stream(const char* p) {
   using V = float __attribute__((ext_vector_type(sizeof(Q) / 4)));
   return __builtin_bit_cast(Q, __builtin_nontemporal_load(reinterpret_cast<const V*>(p)));
 }
+// written once, read once much later (k_detect's burst lists): non-temporal store
+typedef unsigned long long adsb_u64x2 __attribute__((ext_vector_type(2)));
+template <class T>
+__device__ __forceinline__ void adsb_st_stream(T* p, T v) { __builtin_nontemporal_store(v, p); }
 // acc = 16*acc + the four threshold bits (x >= thr, NaN -> 0) of a, b, c, d (a highest): four compares into four
 // scalar pairs, then a chain of add-with-carry (acc = 2*acc + bit).  Batched by four because gfx950 wants two wait
 // states between a vector instruction that writes a scalar pair and a vector instruction that reads it: the three
@@ -190,11 +194,17 @@ struct Slot {
   void* h_ratio = nullptr;       // pinned confidence ratios of the finished call
   size_t h_ratio_cap = 0;
   hipEvent_t done = nullptr, ev0 = nullptr, ev1 = nullptr, det_done = nullptr, h2d_done = nullptr;
+  hipStream_t stream = nullptr;  // this slot's own in-order queue: a SUBMITTED pass runs on it from k_detect to k_compact (see enqueue)
+  hipStream_t ds = nullptr;      // the stream this pass's k_detect was queued on ...
+  hipStream_t cs = nullptr;      // ... and the one its tail, its summary and its record copy run on (the same, or behind an event)
   bool busy = false;
   bool direct = false;           // small pass: k_compact writes the records straight into h_out (no device->host copy)
   bool fused = false;            // ... and the whole pass is ONE launch (k_pass_small)
+  int host_cap = 0;              // mid-size pass: k_compact stores the first host_cap records into h_out as well (see enqueue)
   bool is_shard = false;
+  bool submitted = false;        // queued by adsb_submit_* / the sharded driver (other passes may be in flight beside it)
   bool ev1_valid = false;
+  bool h2d_pending = false;      // host-fed submission: the upload's event has to be waited for by the k_detect stream
   int seq = 0;                   // direct passes: the number the kernel stores into h_sum->pad_ when everything is out
   bool polled = false;           // ... and finish() polls for instead of waiting for an event
   Plan plan{};
@@ -280,9 +290,23 @@ struct adsb_ctx {
   int sps = 0;
   float thr = 0;
   uint32_t flags = 0;
-  hipStream_t stream = nullptr;       // compute
-  hipStream_t copy_stream = nullptr;  // device -> pinned host result copies
-  hipStream_t tail_stream = nullptr;  // everything after k_detect (may overlap the next pass's k_detect)
+  // Queues.  A SUBMITTED pass (adsb_submit_*, the sharded driver) runs on its pipeline slot's own stream, k_detect and its
+  // tail back to back: passes in different slots share nothing, so the hardware overlaps them as resources allow -- the
+  // tail of pass i runs beside k_detect of pass i+1, and k_detect i+1 fills the CUs k_detect i drains from -- without one
+  // event between them (round 5; until then: k_detect of every pass on `stream`, every tail on `tail_stream` behind an
+  // event per pass: 9 us of the 27 us of host time a submission cost, tools/micro/launch_cost.hip).  A BLOCKING call runs
+  // alone, on `stream`, as one queue.  A caller-owned stream (adsb_set_stream) keeps the old arrangement: k_detect on it,
+  // tails on `tail_stream`; so do timed passes and passes over more than 4 GiB, with the slot streams in those roles (enqueue).
+  // Few streams on purpose: the runtime multiplexes streams onto four hardware queues by default, and two streams that share
+  // one serialise.  A context of its own uses three (the slots') plus the upload stream of host-fed submissions;
+  // the record copy of a finished pass goes onto that pass's own -- by then idle -- stream.
+  hipStream_t stream = nullptr;       // compute stream of the blocking entry points: slot 0's stream, or the caller's (adsb_set_stream)
+  hipStream_t copy_stream = nullptr;  // caller-owned compute stream only: device -> pinned host result copies
+  hipStream_t tail_stream = nullptr;  // caller-owned compute stream only: everything after k_detect
+  // adsb_wait_for_event: the caller's events the NEXT pass has to wait for (applied to the stream its first kernel runs on)
+  static constexpr int kMaxExt = 4;
+  hipEvent_t ext_ev[kMaxExt] = {nullptr, nullptr, nullptr, nullptr};
+  int n_ext = 0;
   hipStream_t h2d_stream = nullptr;   // host-fed submissions: sample uploads, back to back on their own stream
   bool split_tail = false;
   bool own_stream = false;
@@ -464,13 +488,13 @@ int ensure_pinned(adsb_ctx* c, void*& p, size_t& cap, size_t bytes, bool coheren
 // k_detect is instantiated per input format and per samples-per-chip of the common rates (2, 4, 8, 20 Msps: the
 // preamble taps become immediate offsets); any other even rate runs the run-time-stride instance
 template <int KMODE>
-void launch_detect_k(adsb_ctx* c, unsigned dyn, const DetectArgs& a, int grid) {
+void launch_detect_k(hipStream_t st, unsigned dyn, const DetectArgs& a, int grid) {
   switch (a.sps) {
-    case 2: hipLaunchKernelGGL((k_detect<KMODE, 1>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
-    case 4: hipLaunchKernelGGL((k_detect<KMODE, 2>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
-    case 8: hipLaunchKernelGGL((k_detect<KMODE, 4>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
-    case 20: hipLaunchKernelGGL((k_detect<KMODE, 10>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
-    default: hipLaunchKernelGGL((k_detect<KMODE, 0>), dim3(grid), dim3(kThreads), dyn, c->stream, a); break;
+    case 2: hipLaunchKernelGGL((k_detect<KMODE, 1>), dim3(grid), dim3(kThreads), dyn, st, a); break;
+    case 4: hipLaunchKernelGGL((k_detect<KMODE, 2>), dim3(grid), dim3(kThreads), dyn, st, a); break;
+    case 8: hipLaunchKernelGGL((k_detect<KMODE, 4>), dim3(grid), dim3(kThreads), dyn, st, a); break;
+    case 20: hipLaunchKernelGGL((k_detect<KMODE, 10>), dim3(grid), dim3(kThreads), dyn, st, a); break;
+    default: hipLaunchKernelGGL((k_detect<KMODE, 0>), dim3(grid), dim3(kThreads), dyn, st, a); break;
   }
 }
 // a power of two whose square, times any integer below 2^15, is an exact float32: what the int8 dot-product instance needs
@@ -480,11 +504,11 @@ bool scale_is_pow2(float s) {
   return m == 0.5f && e > -50 && e < 50;
 }
 template <int MODE>
-void launch_detect(adsb_ctx* c, const DetectArgs& a, int grid) {
+void launch_detect(adsb_ctx* c, hipStream_t st, const DetectArgs& a, int grid) {
   const unsigned dyn = c->det_dyn_lds[MODE];
   // int8 IQ with a power-of-two scale (x / 128 and the like): the instance whose tile loop squares with v_dot4_i32_i8
-  if (MODE == ADSB_FMT_SC8 && scale_is_pow2(a.scale)) launch_detect_k<kModeSc8Pow2>(c, dyn, a, grid);
-  else launch_detect_k<MODE>(c, dyn, a, grid);
+  if (MODE == ADSB_FMT_SC8 && scale_is_pow2(a.scale)) launch_detect_k<kModeSc8Pow2>(st, dyn, a, grid);
+  else launch_detect_k<MODE>(st, dyn, a, grid);
 }
 template <int MODE>
 unsigned detect_static_lds() {
@@ -524,13 +548,21 @@ void launch_confidence(hipStream_t st, int grid, const DetectArgs& a, const Rec*
   hipLaunchKernelGGL((k_confidence<MODE>), dim3(grid), dim3(kThreads), 0, st, a, out, sum, cap, ratio);
 }
 
+// adsb_wait_for_event: the caller's pending events are waited for by `st`, the stream the next call's first operation runs on
+int apply_ext(adsb_ctx* c, hipStream_t st) {
+  for (int i = 0; i < c->n_ext; ++i) HIPCHK(c, hipStreamWaitEvent(st, c->ext_ev[i], 0));
+  c->n_ext = 0;
+  return 0;
+}
+
 // Everything after k_detect (and after k_longrun on the rare second pass): order, gate, compact, records.
 int enqueue_tail(adsb_ctx* c, Slot& s) {
   const DetectArgs& a = s.args;
   const Plan& pl = s.plan;
   Misc* misc = (Misc*)s.d_misc.p;
-  hipStream_t ts = c->stream;
+  hipStream_t ts = s.cs;
   if (s.direct) {
+    ts = s.ds;
     // a small pass (few lists, at most kDirectRecs centres): the whole tail in one workgroup and one launch, on the
     // compute stream right behind its k_detect (nothing to overlap: the pass is a few microseconds of GPU time) -- or,
     // when k_detect itself is a single workgroup of |IQ|^2 float input (a GNU Radio work() call), the whole pass in ONE
@@ -550,15 +582,13 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
     s.polled = true;
     return 0;
   }
-  if (c->split_tail) {
-    // tail on its own stream, ordered after this pass's k_detect/k_longrun only: the next pass's k_detect can
-    // start on the compute stream while this runs
-    // with timing on, the event that closes k_detect's bracket doubles as the dependency (one marker fewer between
-    // consecutive k_detect launches on the compute stream)
+  if (s.ds != s.cs) {
+    // k_detect ran on a stream it shares with the k_detect launches of other passes: the tail, on its own stream, is ordered
+    // after this pass's k_detect only -- the next k_detect can start while it runs.
+    // With timing on, the event that closes k_detect's bracket doubles as the dependency.
     hipEvent_t dep = s.ev1_valid ? s.ev1 : s.det_done;
-    if (!s.ev1_valid) HIPCHK(c, hipEventRecord(dep, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->tail_stream, dep, 0));
-    ts = c->tail_stream;
+    if (!s.ev1_valid) HIPCHK(c, hipEventRecord(dep, s.ds));
+    HIPCHK(c, hipStreamWaitEvent(s.cs, dep, 0));
   }
   // Every tail kernel is small enough to run on a CU BESIDE five resident k_detect workgroups (tests/test_abi.py holds
   // the limits).  Whether it should is a choice: beside the next pass's k_detect the tail finishes ~0.25 ms after its own
@@ -588,15 +618,44 @@ int enqueue_tail(adsb_ctx* c, Slot& s) {
   // host once the `done` event below has completed
   hipLaunchKernelGGL(k_compact, dim3(ag), dim3(kThreads), 0, ts, (const unsigned long long*)sorted, (const Rec*)a.recs, (const unsigned*)sorted_src,
                      &misc->sum, (const int*)s.d_seg.p, fmask, fwant, pl.head_n, (Rec*)(s.direct ? s.h_out : s.d_out.p), (int)s.tot,
-                     a.long_count, a.long_lastp, &misc->acc, s.h_sum);
+                     a.long_count, a.long_lastp, &misc->acc, s.h_sum, (Rec*)(s.host_cap > 0 ? s.h_out : nullptr), s.host_cap);
   HIPCHK(c, hipEventRecord(s.done, ts));
   return 0;
 }
 
 // Queue the whole device pipeline of one plan on the compute stream; nothing here waits for the GPU.
-int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
+int enqueue(adsb_ctx* c, Slot& s, const Plan& pl, bool submitted) {
   HIPCHK(c, hipSetDevice(c->device));
   s.plan = pl;
+  // the queue(s) of this pass (see adsb_ctx): a submitted pass on the slot's own stream; a blocking one alone on the
+  // compute stream; a submitted pass on a caller-owned stream: k_detect there, the tail on the tail stream
+  s.submitted = submitted;
+  s.ds = s.cs = c->stream;
+  if (submitted && c->split_tail) {
+    if (!c->own_stream) {
+      s.cs = c->tail_stream;                     // caller-owned compute stream: k_detect there, every tail on the tail stream
+    } else {
+      s.ds = s.cs = s.stream;
+      // Two kinds of submitted passes keep their k_detect launches one behind the other on a stream of their own (the tail
+      // follows on the slot's stream behind an event -- the arrangement of rounds 2-4):
+      //  * timed ones (ADSB_FLAG_TIMING): the HIP events around k_detect are meant to bracket ONE launch that has the
+      //    machine to itself -- two launches that overlap share the CUs and each reads twice as long;
+      //  * passes over more than 4 GiB of input: a launch of over half a millisecond loses < 1 % in the hand-over to the next,
+      //    and two HBM-bound launches that run side by side cost about that in DRAM locality (complex64, 2^30 samples:
+      //    1.354-1.372 ms chained, 1.375-1.377 overlapped).  Everything smaller gains from the overlap: 2^28 samples +4-5 %,
+      //    2^26 +20 %, 2^24 +38 %; the instruction-bound formats +2-6 % at any size (profiles/r05_ab_queue_arrangements.txt).
+      // No stream is added for that: the three slot streams take the three roles -- slot 0's every k_detect, slot 1's every
+      // tail, slot 2's the record copies (finish) -- because the runtime multiplexes all streams of a process onto FOUR
+      // hardware queues (GPU_MAX_HW_QUEUES), and a k_detect stream that shares its queue with a stream whose tail waits for
+      // that k_detect stalls behind it: with a fourth stream for k_detect the timed 2^28-sample legs ran 10 % slower than
+      // in round 4 (profiles/r05_pass_cost_timed_with_a_fourth_stream.txt).
+      const long long in_bytes = (pl.scan_hi > 0 ? pl.scan_hi : 0) * (long long)mode_bytes(pl.mode);
+      if ((c->flags & ADSB_FLAG_TIMING) || in_bytes > (4ll << 30)) {
+        s.ds = c->slot[0].stream;
+        s.cs = c->slot[1].stream;
+      }
+    }
+  }
   s.span = pl.scan_hi > 0 ? pl.scan_hi : 0;
   // A "unit" (one wavefront) walks one contiguous chunk and owns one output list.
   const int upb = kWaves;                                  // units per workgroup
@@ -628,8 +687,22 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
   // synchronisation at adsb_wait (the 48-byte summary travels the same way); bulk passes keep the DMA copy.
   const long long kDirectRecs = 16384;
   s.direct = s.tot <= kDirectRecs;
+  // A MID-SIZE pass (up to 2^26 samples: tens of microseconds of k_detect, a few thousand records) gets both: k_compact
+  // stores every record into d_out and the first kHostRecs of them ALSO straight into the pinned result buffer.  When the
+  // pass delivers no more than that (the usual case) adsb_wait returns as soon as the tail's event has completed -- no
+  // device->host copy and no second synchronisation (~12 us of a pass whose host side costs 40, tools/pass_cost.py); when
+  // it delivers more, the copy runs as for a bulk pass (d_out is always complete).  Bulk passes are left alone: their
+  // records are megabytes, the DMA engine moves them beside the next pass's kernels.
+  const long long kMidTiles = 65536, kHostRecs = 32768;
+  s.host_cap = 0;
   if (s.direct) { if ((r = ensure_pinned(c, s.h_out, s.h_out_cap, (size_t)s.tot * sizeof(Rec), true))) return r; }
-  else if ((r = ensure(c, s.d_out, (size_t)s.tot * sizeof(Rec)))) return r;
+  else {
+    if ((r = ensure(c, s.d_out, (size_t)s.tot * sizeof(Rec)))) return r;
+    if (ntiles <= kMidTiles) {
+      if ((r = ensure_pinned(c, s.h_out, s.h_out_cap, (size_t)kHostRecs * sizeof(Rec), true))) return r;
+      s.host_cap = (int)kHostRecs;
+    }
+  }
   if ((r = ensure(c, s.d_seg, (size_t)(s.tot / kThreads + 2) * sizeof(int)))) return r;
   if ((r = ensure(c, s.d_blk_count, (size_t)nlists * sizeof(int)))) return r;
   if ((r = ensure(c, s.d_blk_lastp, (size_t)nlists * sizeof(long long)))) return r;
@@ -640,7 +713,7 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
     if ((r = ensure(c, s.d_misc, sizeof(Misc)))) return r;
     // on the compute stream (the context's streams are non-blocking: a legacy-stream memset would not be ordered
     // before the first k_detect); afterwards k_compact re-zeroes the list head every pass
-    HIPCHK(c, hipMemsetAsync(s.d_misc.p, 0, sizeof(Misc), c->stream));
+    HIPCHK(c, hipMemsetAsync(s.d_misc.p, 0, sizeof(Misc), s.ds));
   }
   Misc* misc = (Misc*)s.d_misc.p;
 
@@ -655,10 +728,13 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl) {
 
   const bool timing = (c->flags & ADSB_FLAG_TIMING) != 0;
   s.fused = s.direct && grid == 1 && pl.mode == ADSB_FMT_MAG2 && !timing;
+  // what this pass's first kernel has to wait for: its own upload (host-fed submission), the caller's events (adsb_wait_for_event)
+  if (s.h2d_pending) { HIPCHK(c, hipStreamWaitEvent(s.ds, s.h2d_done, 0)); s.h2d_pending = false; }
+  { int r_ = apply_ext(c, s.ds); if (r_) return r_; }
   if (!s.fused) {
-    if (timing) HIPCHK(c, hipEventRecord(s.ev0, c->stream));
-    ADSB_BY_MODE(pl.mode, launch_detect, c, a, grid);
-    if (timing) HIPCHK(c, hipEventRecord(s.ev1, c->stream));
+    if (timing) HIPCHK(c, hipEventRecord(s.ev0, s.ds));
+    ADSB_BY_MODE(pl.mode, launch_detect, c, s.ds, a, grid);
+    if (timing) HIPCHK(c, hipEventRecord(s.ev1, s.ds));
   }
   c->stats.detect_grid = (uint64_t)grid; c->stats.blocks_per_cu = (uint64_t)c->bpc[pl.mode];
   c->stats.calls++;
@@ -695,7 +771,7 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
       }
       std::atomic_thread_fence(std::memory_order_acquire);
       if (*seqp != s.seq) {
-        FINCHK(hipStreamSynchronize(c->stream));
+        FINCHK(hipStreamSynchronize(s.ds));
         FINCHK(hipGetLastError());
         std::atomic_thread_fence(std::memory_order_acquire);
         if (*seqp != s.seq) { s.busy = false; return fail(c, -EIO, "small pass finished without publishing its summary"); }
@@ -730,7 +806,7 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
       if ((long long)s.rec_cap >= s.chunk / 2 + 8) { s.busy = false; return fail(c, -EIO, "centre list overflow at maximum size"); }
       c->rec_cap_shift++;
       c->stats.retries++;
-      int r = enqueue(c, s, s.plan);
+      int r = enqueue(c, s, s.plan, s.submitted);
       if (r) { s.busy = false; return r; }
       c->stats.calls--;
       continue;
@@ -739,25 +815,30 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
     if (s.h_sum->long_count > s.args.long_cap) { s.busy = false; return fail(c, -EIO, "long-rise list overflow"); }
     *sum = *s.h_sum;
     const int nres = sum->n_kept;
-    int r = s.direct ? 0 : ensure_pinned(c, s.h_out, s.h_out_cap, (size_t)(nres > 0 ? nres : 1) * sizeof(Rec), true);
+    // the records are already in h_out: a one-workgroup pass (all of them), or a mid-size pass that delivered no more than
+    // k_compact stored there beside d_out (enqueue)
+    const bool in_host = (s.direct || nres <= s.host_cap) && s.h_out != nullptr;
+    int r = in_host ? 0 : ensure_pinned(c, s.h_out, s.h_out_cap, (size_t)(nres > 0 ? nres : 1) * sizeof(Rec), true);
     if (r) { s.busy = false; return r; }
     const Rec* recs_dev = (const Rec*)(s.direct ? s.h_out : s.d_out.p);
-    if (nres > 0 && (!s.direct || (c->flags & ADSB_FLAG_CONFIDENCE))) {
-      if (!s.direct)
-        FINCHK(hipMemcpyAsync(s.h_out, s.d_out.p, (size_t)nres * sizeof(Rec), hipMemcpyDeviceToHost, c->copy_stream));
+    if (nres > 0 && (!in_host || (c->flags & ADSB_FLAG_CONFIDENCE))) {
+      // on the pass's own stream (idle: its last kernel has completed); never on a caller-owned one
+      const hipStream_t xs = !c->own_stream ? c->copy_stream : (s.ds != s.cs ? c->slot[2].stream : s.cs);
+      if (!in_host)
+        FINCHK(hipMemcpyAsync(s.h_out, s.d_out.p, (size_t)nres * sizeof(Rec), hipMemcpyDeviceToHost, xs));
       if (c->flags & ADSB_FLAG_CONFIDENCE) {
         // opt-in (demod.py:97-101): bit1/bit0 ratios of the delivered records, computed now that their number is
         // known -- one more small kernel and copy on the copy stream, paid only by callers who ask for it
         const size_t rb = (size_t)nres * 112 * sizeof(float);
         if ((r = ensure(c, s.d_ratio, rb)) || (r = ensure_pinned(c, s.h_ratio, s.h_ratio_cap, rb))) { s.busy = false; return r; }
-        FINCHK(hipMemsetAsync(s.d_ratio.p, 0, rb, c->copy_stream));
+        FINCHK(hipMemsetAsync(s.d_ratio.p, 0, rb, xs));
         int cg = (nres + kWaves - 1) / kWaves;
         if (cg > c->n_cu * 8) cg = c->n_cu * 8;
-        ADSB_BY_MODE(s.plan.mode, launch_confidence, c->copy_stream, cg, s.args, recs_dev,
+        ADSB_BY_MODE(s.plan.mode, launch_confidence, xs, cg, s.args, recs_dev,
                      (const Summary*)&((Misc*)s.d_misc.p)->sum, nres, (float*)s.d_ratio.p);
-        FINCHK(hipMemcpyAsync(s.h_ratio, s.d_ratio.p, rb, hipMemcpyDeviceToHost, c->copy_stream));
+        FINCHK(hipMemcpyAsync(s.h_ratio, s.d_ratio.p, rb, hipMemcpyDeviceToHost, xs));
       }
-      FINCHK(hipStreamSynchronize(c->copy_stream));
+      FINCHK(hipStreamSynchronize(xs));
       FINCHK(hipGetLastError());
     }
     s.nres = nres;
@@ -775,7 +856,7 @@ int run_pipeline(adsb_ctx* c, const Plan& pl, Summary* sum, int32_t* n_res) {
   for (const Slot& sl : c->slot) if (sl.busy) return fail(c, -EBUSY, "a submitted call is still pending (adsb_wait first)");
   Slot& s = c->slot[0];
   c->last_slot = 0;
-  int r = enqueue(c, s, pl);
+  int r = enqueue(c, s, pl, false);
   if (r) { s.busy = false; return r; }
   return finish(c, s, sum, n_res);
 }
@@ -866,6 +947,7 @@ int staged_copy(adsb_ctx* c, void* d_dst, const void* host, size_t bytes, hipStr
 int upload(adsb_ctx* c, const void* host, size_t bytes, void** d_out) {
   const size_t kZeroCopyBytes = (size_t)256 << 10;
   int rc;
+  if ((rc = apply_ext(c, c->stream))) return rc;
   const void* src = host;
   const bool pinned = is_pinned_host(host);
   const bool small = bytes <= kZeroCopyBytes;
@@ -962,23 +1044,22 @@ int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx
       c->lds_beside[m] = used < 163840u ? 163840u - used : 0u;
     }
   }
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return -EIO; }
   c->own_stream = true;
-  if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { adsb_destroy(c); return -EIO; }
-  if (hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking) != hipSuccess) { adsb_destroy(c); return -EIO; }
-  if (hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking) != hipSuccess) { adsb_destroy(c); return -EIO; }
-  // the sparse tail of a pass runs on its own stream beside the next pass's k_detect unless the caller opts out
+  // submitted passes overlap on the slots' streams unless the caller opts out (ADSB_FLAG_SINGLE_STREAM: everything on ONE stream)
   c->split_tail = (flags & ADSB_FLAG_SINGLE_STREAM) == 0;
   for (hipEvent_t& e : c->ring_done)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { adsb_destroy(c); return -EIO; }
   for (Slot& sl : c->slot) {
     if (host_alloc_near(c, (void**)&sl.h_sum, sizeof(Summary), true) != hipSuccess) { adsb_destroy(c); return -ENOMEM; }
     memset(sl.h_sum, 0, sizeof(Summary));                        // (pad_ is the pass number finish() polls: starts at zero)
+    if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess) { adsb_destroy(c); return -EIO; }
     if (hipEventCreate(&sl.ev0) != hipSuccess || hipEventCreate(&sl.ev1) != hipSuccess ||
         hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&sl.det_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming) != hipSuccess) { adsb_destroy(c); return -EIO; }
   }
+  c->stream = c->slot[0].stream;         // blocking calls always run in slot 0 (run_pipeline)
+  if (hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking) != hipSuccess) { adsb_destroy(c); return -EIO; }
   *out = c;
   return 0;
 }
@@ -986,10 +1067,11 @@ int adsb_create(double fs, float threshold, int device, uint32_t flags, adsb_ctx
 void adsb_destroy(adsb_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (!c->own_stream && c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   if (c->h2d_stream) (void)hipStreamSynchronize(c->h2d_stream);
   if (c->tail_stream) (void)hipStreamSynchronize(c->tail_stream);
+  for (Slot& sl : c->slot) if (sl.stream) (void)hipStreamSynchronize(sl.stream);
   DevBuf* bufs[] = {&c->d_in};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (Slot& sl : c->slot) {
@@ -1004,6 +1086,7 @@ void adsb_destroy(adsb_ctx* c) {
     if (sl.ev1) (void)hipEventDestroy(sl.ev1);
     if (sl.done) (void)hipEventDestroy(sl.done);
     if (sl.det_done) (void)hipEventDestroy(sl.det_done);
+    if (sl.stream) (void)hipStreamDestroy(sl.stream);
   }
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_dm) (void)hipHostFree(c->h_dm);
@@ -1013,7 +1096,6 @@ void adsb_destroy(adsb_ctx* c) {
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
   if (c->tail_stream) (void)hipStreamDestroy(c->tail_stream);
-  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -1026,7 +1108,10 @@ int adsb_set_threshold(adsb_ctx* c, float threshold) {
 int adsb_set_stream(adsb_ctx* c, void* hip_stream) {
   if (!c) return -EINVAL;
   for (const Slot& sl : c->slot) if (sl.busy) return fail(c, -EBUSY, "calls pending");
-  if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  if (c->own_stream && c->stream) (void)hipStreamSynchronize(c->stream);      // (slot 0's: it stays the slot's)
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!c->tail_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking));
   c->stream = (hipStream_t)hip_stream;
   c->own_stream = false;
   return 0;
@@ -1064,9 +1149,18 @@ int adsb_host_copy(adsb_ctx* c, void* dst, const void* src, size_t bytes) {
 int adsb_wait_for_event(adsb_ctx* c, void* hip_event) {
   if (!c || !hip_event) return -EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
-  // whatever is submitted next (kernels on the compute stream, uploads on the upload stream) runs after the event
-  HIPCHK(c, hipStreamWaitEvent(c->stream, (hipEvent_t)hip_event, 0));
-  HIPCHK(c, hipStreamWaitEvent(c->h2d_stream, (hipEvent_t)hip_event, 0));
+  // The NEXT call -- blocking, submitted or host-fed -- runs after the event: the wait is queued with that call, on the stream
+  // its first operation runs on (which one is decided there; a host-fed submission: the upload stream).  Nothing is queued
+  // now: a stream that is never used never takes one of the process's four hardware queues.  The event has to stay alive
+  // until that call; a later submission that depends on the same producer asks again (FrontEnd does, per tensor call).
+  if (c->n_ext == adsb_ctx::kMaxExt) {           // more producers than remembered: the oldest is waited for by every queue now
+    for (Slot& sl : c->slot) HIPCHK(c, hipStreamWaitEvent(sl.stream, c->ext_ev[0], 0));
+    if (!c->own_stream) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ext_ev[0], 0));
+    HIPCHK(c, hipStreamWaitEvent(c->h2d_stream, c->ext_ev[0], 0));
+    for (int i = 1; i < c->n_ext; ++i) c->ext_ev[i - 1] = c->ext_ev[i];
+    --c->n_ext;
+  }
+  c->ext_ev[c->n_ext++] = (hipEvent_t)hip_event;
   return 0;
 }
 
@@ -1165,7 +1259,7 @@ static int submit_canonical(adsb_ctx* c, int mode, const void* d_data, int64_t n
   if (s.busy) return fail(c, -EBUSY, "every pipeline slot is in flight (adsb_wait first)");
   Plan pl = plan_canonical(mode, d_data, n, abs_offset, c->sps);
   pl.long_aware = (c->flags & ADSB_FLAG_LONG_AWARE_GATE) != 0;
-  int r = enqueue(c, s, pl);
+  int r = enqueue(c, s, pl, true);
   if (r) { s.busy = false; return r; }
   s.is_shard = false;
   *ticket = c->next_slot;
@@ -1178,6 +1272,7 @@ static int submit_canonical(adsb_ctx* c, int mode, const void* d_data, int64_t n
 // chunk k+1 (split over the context's copy threads) runs beside the DMA of chunk k.
 static int upload_async(adsb_ctx* c, Slot& s, const void* host, size_t bytes) {
   int rc;
+  if ((rc = apply_ext(c, c->h2d_stream))) return rc;     // (the kernels come behind the upload: they need no wait of their own)
   if ((rc = ensure(c, s.d_in, bytes + 64))) return rc;
   if (is_pinned_host(host)) {
     HIPCHK(c, hipMemcpyAsync(s.d_in.p, host, bytes, hipMemcpyHostToDevice, c->h2d_stream));
@@ -1185,7 +1280,7 @@ static int upload_async(adsb_ctx* c, Slot& s, const void* host, size_t bytes) {
     return rc;
   }
   HIPCHK(c, hipEventRecord(s.h2d_done, c->h2d_stream));
-  HIPCHK(c, hipStreamWaitEvent(c->stream, s.h2d_done, 0));
+  s.h2d_pending = true;          // enqueue() makes the stream this pass's k_detect runs on wait for it
   return 0;
 }
 
@@ -1389,11 +1484,132 @@ int adsb_submit_shard_device(adsb_ctx* c, int fmt, const void* d_data, int64_t n
   if (rc) return rc;
   Slot& s = c->slot[c->next_slot];
   if (s.busy) return fail(c, -EBUSY, "every pipeline slot is in flight (adsb_wait first)");
-  rc = enqueue(c, s, pl);
+  rc = enqueue(c, s, pl, true);
   if (rc) { s.busy = false; return rc; }
   s.is_shard = true;
   *ticket = c->next_slot;
   c->next_slot = (c->next_slot + 1) % ADSB_MAX_IN_FLIGHT;
+  return 0;
+}
+
+int32_t adsb_shard_bounds(int64_t stream_len, int32_t n_shards, int32_t g, int sps, int64_t align, int64_t* own_lo,
+                          int64_t* own_hi, int64_t* lo, int64_t* hi) {
+  // The tiling of gr_adsb_amd/frontend.py: shard_plan (one rule for every caller: bench.py's ranks, file replay, the C
+  // driver below): equal owner ranges of a multiple of `align` samples; back halo = noise window + preamble span + 4
+  // (framer.py:31,137-147), buffer start on a 16-byte boundary of every format; forward halo = longest pulse followed (256)
+  // + preamble and 112 bits (121*sps: framer.py:165, demod.py:76).
+  if (stream_len < 0 || n_shards < 1 || g < 0 || g >= n_shards || sps < 2 || align < 1 || !own_lo || !own_hi || !lo || !hi) return -EINVAL;
+  long long per = (stream_len + n_shards - 1) / n_shards;
+  per = (per + align - 1) / align * align;
+  const long long olo = (long long)g * per < stream_len ? (long long)g * per : stream_len;
+  const long long ohi = (long long)(g + 1) * per < stream_len ? (long long)(g + 1) * per : stream_len;
+  long long l = olo - (kNoise + 8ll * sps + 4);
+  if (l < 0) l = 0;
+  l -= l % 4;
+  long long h = ohi + 256 + 121ll * sps;
+  if (h > stream_len) h = stream_len;
+  *own_lo = olo; *own_hi = ohi; *lo = l; *hi = h;
+  return 0;
+}
+
+// the plain greedy gate (framer.py:121-123,165) over a shard's UNGATED centres with the incoming end-of-burst state: the
+// fallback for a shard whose head region ends inside an unbroken chain of overlapping bursts
+static int32_t gate_from(adsb_burst* recs, int32_t n, int sps, long long* eob_io) {
+  long long eob = *eob_io;
+  int32_t w = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    if (recs[i].offset > eob) {
+      eob = recs[i].offset + ((recs[i].flags & ADSB_BURST_LONG_HINT) ? 119ll : 63ll) * sps;
+      adsb_burst b = recs[i];
+      b.flags = (uint16_t)((b.flags | ADSB_BURST_KEPT) & ~ADSB_BURST_HEAD);
+      recs[w++] = b;
+    }
+  }
+  *eob_io = eob;
+  return w;
+}
+
+int adsb_process_sharded_device(adsb_ctx* c, int fmt, const void* d_data, int64_t n, int64_t abs_offset, int32_t shards,
+                                adsb_burst* out, int32_t cap, int32_t* n_out) {
+  if (!c || fmt < 0 || fmt >= ADSB_FMT_COUNT || n < 0 || shards < 1 || cap < 0 || (cap > 0 && !out) || !n_out) return -EINVAL;
+  if (((uintptr_t)d_data & 15u) != 0) return fail(c, -EINVAL, "device pointer must be 16-byte aligned");
+  for (const Slot& sl : c->slot) if (sl.busy) return fail(c, -EBUSY, "a submitted call is still pending (adsb_wait first)");
+  *n_out = 0;
+  if (n == 0) return 0;
+  const int bps = mode_bytes(fmt);
+  struct Pend { int ticket; long long own_lo, own_hi, lo, hi; };
+  Pend pend[ADSB_MAX_IN_FLIGHT];
+  int n_pend = 0, head = 0;
+  long long eob = -(1ll << 60);
+  int64_t total = 0;
+  int rc = 0;
+  const int kHead = 64;
+
+  // collect the oldest pass: fix up its head with the carried state, append what it kept
+  auto collect = [&]() -> int {
+    const Pend p = pend[head];
+    head = (head + 1) % ADSB_MAX_IN_FLIGHT; --n_pend;
+    Slot& s = c->slot[p.ticket];
+    Summary sum;
+    int32_t nres = 0;
+    int r = finish(c, s, &sum, &nres);
+    if (r) return r;
+    c->last_slot = p.ticket;
+    if ((r = shard_post(c, s, sum, &nres))) return r;
+    adsb_burst* recs = (adsb_burst*)s.h_out;
+    int32_t kept = 0;
+    r = adsb_shard_fixup(recs, nres, c->sps, eob, &kept);
+    if (r == -EAGAIN) {
+      // the head region ended inside a chain: this shard again on the slot that has just become free -- first with the
+      // largest head, then ungated with the plain greedy gate (exact in every case)
+      for (int attempt = 0; attempt < 2 && r == -EAGAIN; ++attempt) {
+        Plan pl;
+        if ((r = shard_plan_checked(c, fmt, (const char*)d_data + (size_t)p.lo * bps, p.hi - p.lo, p.lo, p.own_lo, p.own_hi, n,
+                                    attempt == 0 ? 4096 : 0, &pl))) return r;
+        if ((r = enqueue(c, s, pl, true))) { s.busy = false; return r; }
+        if ((r = finish(c, s, &sum, &nres))) return r;
+        if ((r = shard_post(c, s, sum, &nres))) return r;
+        recs = (adsb_burst*)s.h_out;
+        if (attempt == 0) r = adsb_shard_fixup(recs, nres, c->sps, eob, &kept);
+        else { long long e = eob; kept = gate_from(recs, nres, c->sps, &e); r = 0; }
+      }
+      if (r) return r;
+      c->stats.shard_fallbacks++;
+    } else if (r) return fail(c, r, "adsb_shard_fixup");
+    if (kept > 0) {
+      const adsb_burst& last = recs[kept - 1];
+      eob = last.offset + ((last.flags & ADSB_BURST_LONG_HINT) ? 119ll : 63ll) * c->sps;
+      if (total + kept <= cap) {
+        memcpy(out + total, recs, (size_t)kept * sizeof(adsb_burst));
+        if (abs_offset) for (int32_t i = 0; i < kept; ++i) out[total + i].offset += abs_offset;
+      }
+    }
+    total += kept;
+    s.nres = kept;
+    return 0;
+  };
+
+  for (int32_t g = 0; g < shards && !rc; ++g) {
+    int64_t own_lo, own_hi, lo, hi;
+    if ((rc = adsb_shard_bounds(n, shards, g, c->sps, 4096, &own_lo, &own_hi, &lo, &hi))) break;
+    if (own_hi <= own_lo) continue;
+    if (n_pend == ADSB_MAX_IN_FLIGHT && (rc = collect())) break;
+    Plan pl;
+    if ((rc = shard_plan_checked(c, fmt, (const char*)d_data + (size_t)lo * bps, hi - lo, lo, own_lo, own_hi, n, kHead, &pl))) break;
+    Slot& s = c->slot[c->next_slot];
+    if ((rc = enqueue(c, s, pl, true))) { s.busy = false; break; }
+    s.is_shard = true;
+    pend[(head + n_pend) % ADSB_MAX_IN_FLIGHT] = Pend{c->next_slot, own_lo, own_hi, lo, hi};
+    ++n_pend;
+    c->next_slot = (c->next_slot + 1) % ADSB_MAX_IN_FLIGHT;
+  }
+  while (n_pend > 0) {
+    const int r = collect();          // (after an error too: no pass stays in flight behind this call)
+    if (r && !rc) rc = r;
+  }
+  if (rc) return rc;
+  *n_out = (int32_t)(total > 0x7FFFFFFF ? 0x7FFFFFFF : total);
+  if (total > cap) return fail(c, -ENOSPC, "output array too small");
   return 0;
 }
 

@@ -114,6 +114,12 @@ class FrontEnd:
         _after_torch(self.ctx, t)
         return self.ctx.submit_shard_device(fmt, t.data_ptr(), t.shape[0], origin, own_lo, own_hi, stream_len, head_cands)
 
+    def process_sharded_tensor(self, fmt, t, shards, abs_offset=0, out=None):
+        """t as `shards` overlapped time shards on this GPU, pipelined and stitched in C (adsb_process_sharded_device):
+        bit-identical to process_format_tensor over the whole tensor."""
+        _after_torch(self.ctx, t)
+        return self.ctx.process_sharded_device(fmt, t.data_ptr(), t.shape[0], shards, abs_offset, out=out)
+
     def wait(self, ticket, fetch=True, copy=True):
         return self.ctx.wait(ticket, fetch=fetch, copy=copy)
 

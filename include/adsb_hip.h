@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ADSB_ABI_VERSION 3
+#define ADSB_ABI_VERSION 4
 #define ADSB_MAX_SPS 100 /* highest sample rate accepted: 100 Msps (tested up to and including it against the reference) */
 #ifndef ADSB_MAX_IN_FLIGHT
 #define ADSB_MAX_IN_FLIGHT 3 /* adsb_submit_* calls that may be pending at once */
@@ -124,6 +124,8 @@ typedef struct adsb_stats {
   uint64_t longrun_pulses;   /* pulses longer than k_detect's LDS window, handled by the long-pulse kernel (sum over calls) */
   uint64_t poll_fallbacks;   /* ABI 3: small passes whose pass number did not appear within the short spin and were waited for
                               * by blocking on the stream instead (adsb_hip.hip: finish) */
+  uint64_t shard_fallbacks;  /* ABI 4: shards of adsb_process_sharded_device whose head region ended inside a chain of overlapping
+                              * bursts and were run a second time (larger head, then ungated + greedy gate) */
 } adsb_stats;
 
 int adsb_abi_version(void);
@@ -150,9 +152,11 @@ int adsb_set_copy_threads(adsb_ctx* ctx, int32_t threads);
 /* memcpy split over the context's copy threads (the GNU Radio passthrough `out0[:] = in0` of multi-megabyte chunks:
  * framer.py:181, demod.py:135).  Plain host memory on both sides; blocking. */
 int adsb_host_copy(adsb_ctx* ctx, void* dst, const void* src, size_t bytes);
-/* Order everything submitted to this context AFTER a HIP event of the caller (hipEvent_t recorded on the stream that
- * produces a device-resident input, e.g. a framework's current stream): a device-side dependency, the host does not
- * wait.  The event may be destroyed once the next call on the context has returned. */
+/* Order the NEXT call on this context -- blocking, adsb_submit_* or the sharded driver's first pass -- AFTER a HIP event of the
+ * caller (hipEvent_t recorded on the stream that produces a device-resident input, e.g. a framework's current stream): a
+ * device-side dependency, the host does not wait.  ABI 4: submitted passes run on one stream per pipeline slot, so the wait is
+ * queued with that next call, on the stream its first operation runs on (a host-fed submission: the upload stream); a later submission that depends on the same producer asks again.  Up to four events may be pending.  The
+ * event must stay alive until that next call has returned. */
 int adsb_wait_for_event(adsb_ctx* ctx, void* hip_event);
 /* Forget the framer's cross-call state (prev_in0 = 0, prev_eob = -1; framer.py:54,57). */
 int adsb_reset(adsb_ctx* ctx);
@@ -279,6 +283,25 @@ int adsb_shard_device(adsb_ctx* ctx, int fmt, const void* d_data, int64_t n, int
 int adsb_shard_host(adsb_ctx* ctx, int fmt, const void* host, int64_t n, int64_t origin, int64_t own_lo,
                     int64_t own_hi, int64_t stream_len, int32_t head_cands, uint32_t shard_flags,
                     adsb_burst* out, int32_t cap, int32_t* n_out);
+/* The tiling every sharded caller uses (gr_adsb_amd/frontend.py: shard_plan; bench.py's ranks; file replay; the driver
+ * below): shard g of n_shards over a stream of stream_len samples owns the pulse rises of [*own_lo, *own_hi) -- equal
+ * ranges of a multiple of `align` samples -- and needs the samples [*lo, *hi): 100 + 8*sps + 4 of back halo (noise window,
+ * framer.py:31,156; preamble span), *lo on a 16-byte boundary of every format, and 256 + 121*sps of forward halo (the longest
+ * pulse followed, preamble + 112 bits: framer.py:165, demod.py:76).  Pure host arithmetic; 0 or -EINVAL. */
+int32_t adsb_shard_bounds(int64_t stream_len, int32_t n_shards, int32_t g, int sps, int64_t align, int64_t* own_lo,
+                          int64_t* own_hi, int64_t* lo, int64_t* hi);
+/* ONE resident stream processed as `shards` overlapped time shards on THIS device -- BASELINE config 4's decomposition
+ * (one 20 Msps stream tiled as N overlapped shards) run where there is one GPU, or many receivers' worth of mid-size
+ * buffers multiplexed on it: the shards are planned (adsb_shard_bounds, align 4096), kept ADSB_MAX_IN_FLIGHT deep in the
+ * pipeline, each detected and gated on the device as a fresh stream; the head of every shard is re-gated on the host with
+ * the end-of-burst state carried from the shard in front of it (adsb_shard_fixup; a head that ends inside a chain of
+ * overlapping bursts: the shard once more with the largest head, then ungated with the plain greedy gate).  The whole loop
+ * is host C: no interpreter between two passes.  Result: bit-identical to adsb_process_format_device over the whole
+ * buffer (records, order, flags except ADSB_BURST_HEAD, which is cleared).  out must hold the result (-ENOSPC with *n_out =
+ * the number needed otherwise).  Replaces: one framer.work() + demod.work() over the stream (framer.py:72-182,
+ * demod.py:57-136), like adsb_process_format_device; the tiling itself has no reference counterpart. */
+int adsb_process_sharded_device(adsb_ctx* ctx, int format, const void* d_data, int64_t n, int64_t abs_offset,
+                                int32_t shards, adsb_burst* out, int32_t cap, int32_t* n_out);
 /* eob_in = (offset of the last burst kept before this shard) + 63*sps, or a very negative number for the
  * first shard.  Compacts recs in place to the exact kept list; -EAGAIN if the head region was too short
  * (call adsb_shard_device again with a larger head_cands, or with 0 and adsb_stitch). */

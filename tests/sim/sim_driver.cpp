@@ -138,10 +138,23 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
     }
     hipsim::launch(k_count, 3, kThreads, (const unsigned long long*)sorted.data(), (const Summary*)&sum, fmask, fwant,
                    head_n, seg.data());
+    // mid-size passes of the library: the first host_cap records also go to the pinned result buffer (here: three, so that
+    // vectors with more survivors than that cross the boundary)
+    constexpr int kHostCap = 3;
+    std::vector<Rec> host_first(kHostCap);
+    memset(host_first.data(), 0xEE, kHostCap * sizeof(Rec));
     hipsim::launch(k_compact, 3, kThreads, (const unsigned long long*)sorted.data(), (const Rec*)recs.data(), (const unsigned*)sorted_src.data(), &sum,
-                   (const int*)seg.data(), fmask, fwant, head_n, outv.data(), (int)tot, &long_count, &long_lastp, &acc, &sum_host);
+                   (const int*)seg.data(), fmask, fwant, head_n, outv.data(), (int)tot, &long_count, &long_lastp, &acc, &sum_host,
+                   host_first.data(), kHostCap);
     if (acc.flags != 0u || acc.lastp_biased != 0ull) return -7;     // left clean for the slot's next pass
     sum = sum_host;
+    {
+      const int nh = sum.n_kept < kHostCap ? sum.n_kept : kHostCap;
+      if (nh > 0 && memcmp(host_first.data(), outv.data(), (size_t)nh * sizeof(Rec)) != 0) return -9;
+      for (int i = nh; i < kHostCap; ++i)
+        for (size_t b = 0; b < sizeof(Rec); ++b)
+          if (((const unsigned char*)&host_first[i])[b] != 0xEE) return -9;     // nothing stored past the survivors
+    }
     if (g_conf_out) SIM_BY_MODE(mode, k_confidence, 2, kThreads, a, (const Rec*)outv.data(), (const Summary*)&sum, (int)tot, g_conf_out);
   }
   so->n_rec = sum.n_rec; so->n_kept = sum.n_kept; so->overflow = sum.overflow; so->long_count = sum.long_count;

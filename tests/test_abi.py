@@ -31,13 +31,13 @@ def test_library_exports_every_declared_symbol(native):
     for n in names:
         assert hasattr(lib, n), "missing export " + n
     assert set(names) == set(native.EXPORTS)
-    assert lib.adsb_abi_version() == native.ABI_VERSION == 3
+    assert lib.adsb_abi_version() == native.ABI_VERSION == 4
 
 
 def test_struct_layouts(native):
     assert native.BURST_DTYPE.itemsize == 32
     assert native.BURST_DTYPE.fields["bits"][1] == 16 and native.BURST_DTYPE.fields["flags"][1] == 30
-    assert ctypes.sizeof(native.Stats) == 104          # ABI 3: + poll_fallbacks
+    assert ctypes.sizeof(native.Stats) == 112          # ABI 3: + poll_fallbacks; ABI 4: + shard_fallbacks
 
 
 def test_no_cpu_fallback_without_device(native):
@@ -236,3 +236,20 @@ def test_chunk_plan_covers_the_call_and_keeps_its_limits(native):
         native.plan_chunks(-1, 5120)
     with pytest.raises(native.AdsbError):
         native.plan_chunks(1 << 20, 0)
+
+
+def test_shard_bounds_is_the_python_tiling():
+    """adsb_shard_bounds (round 5: the tiling the C sharded driver uses) == frontend.shard_plan (what bench.py's ranks and
+    file replay use), on the CPU: pure host arithmetic."""
+    import random
+    from gr_adsb_amd import _native as native
+    from gr_adsb_amd.frontend import shard_plan
+    rnd = random.Random(5)
+    for _ in range(3000):
+        L = rnd.choice([0, 1, 5, 4095, 4096, 4097, rnd.randrange(1, 1 << 34)])
+        k, sps, al = rnd.randrange(1, 17), rnd.choice([2, 4, 8, 20, 100]), rnd.choice([4, 4096, 1 << 20])
+        for g, pl in enumerate(shard_plan(L, k, sps, align=al)):
+            assert native.shard_bounds(L, k, g, sps, al) == (pl["own_lo"], pl["own_hi"], pl["lo"], pl["hi"])
+    for bad in ((-1, 1, 0, 2, 4), (10, 0, 0, 2, 4), (10, 2, 2, 2, 4), (10, 2, 0, 1, 4), (10, 2, 0, 2, 0)):
+        with pytest.raises(native.AdsbError):
+            native.shard_bounds(*bad)

@@ -745,6 +745,88 @@ def test_overlapped_shards_stitch_equals_single_call(native, torch_mod, fs, bps,
     assert np.array_equal(fixed["flags"] & 3, whole["flags"] & 3)
 
 
+@pytest.mark.parametrize("fs,bps,log2n,shards,seed", [(20e6, 2000, 23, 8, 8), (2e6, 3000, 21, 8, 9), (8e6, 6000, 21, 3, 10),
+                                                      (2e6, -32, 20, 3, 11), (8e6, -16, 19, 4, 14), (2e6, 1000, 14, 5, 12), (20e6, 1000, 22, 1, 13)])
+def test_sharded_driver_in_c_equals_single_call(native, torch_mod, fs, bps, log2n, shards, seed):
+    """adsb_process_sharded_device (round 5): BASELINE config 4's decomposition with the whole submit / wait / fix-up loop in
+    C.  Bit-identical to one canonical call and to the C oracle.  bps < 0: a train of bare preambles every -bps symbols -- ONE
+    unbroken chain of centres inside each other's gate over the whole stream, thousands per shard -- so every shard takes the
+    fallback (the largest head, then ungated + the plain greedy gate)."""
+    from gr_adsb_amd import modulator as M
+    from gr_adsb_amd.frontend import FrontEnd
+    from oracle import c_oracle as C
+    n = (1 << log2n) - 3 * (seed % 4)             # ragged lengths too
+    thr = 0.01
+    sps = int(fs // 1e6)
+    iq = M.synth_iq(n, fs, bps, seed=seed) if bps > 0 else preamble_train_iq(n, spacing=-bps, sps=sps, seed=seed)
+    fe = FrontEnd(fs, thr)
+    t = to_dev(torch_mod, iq)
+    whole = fe.process_iq_tensor(t)
+    assert_recs_equal(whole, C.process_iq(iq, sps, thr), "whole")
+    assert len(whole) > 3
+    got = fe.process_sharded_tensor(native.FMT_FC32, t, shards)
+    assert np.array_equal(got["flags"] & native.BURST_HEAD, np.zeros(len(got), np.uint16))
+    assert_recs_equal(got, whole, "sharded in C")
+    assert np.array_equal(got["flags"] & 0x1FE3, whole["flags"] & 0x1FE3)      # KEPT, DEMOD and the pre-filter bits
+    if bps < 0:
+        assert fe.stats()["shard_fallbacks"] >= shards - 1        # (the first shard's incoming state is "none": it may pass)
+    # an output array that is too small: -ENOSPC with the number needed, then the binding grows it
+    small = np.empty(2, dtype=native.BURST_DTYPE)
+    again = fe.process_sharded_tensor(native.FMT_FC32, t, shards, out=small)
+    assert again.tobytes() == got.tobytes()
+    # stream offsets shifted like the canonical call's abs_offset; the context stays usable for ordinary calls
+    off = fe.process_sharded_tensor(native.FMT_FC32, t, shards, abs_offset=12345)
+    assert np.array_equal(off["offset"], whole["offset"] + 12345) and np.array_equal(off["bits"], whole["bits"])
+    assert fe.process_iq_tensor(t).tobytes() == whole.tobytes()
+
+
+def test_sharded_driver_other_formats(native, torch_mod):
+    """The same through the int8 and |IQ|^2 entry formats (buffer starts of the shards on 16-byte boundaries of 2- and
+    4-byte samples)."""
+    from gr_adsb_amd import modulator as M
+    from gr_adsb_amd.frontend import FrontEnd
+    from oracle import adsb_oracle as O
+    fs, n = 8e6, (1 << 21) + 40
+    iq = M.synth_iq(n, fs, 3000, seed=21)
+    fe = FrontEnd(fs, 0.01)
+    x = torch_mod.from_numpy(O.mag2(iq)).to("cuda:0")
+    assert fe.process_sharded_tensor(native.FMT_MAG2, x, 7).tobytes() == _clear_head(native, fe.process_mag2_tensor(x)).tobytes()
+    q = np.clip(np.round(iq.view(np.float32) * 32.0), -127, 127).astype(np.int8).reshape(-1, 2)
+    fe.ctx.set_format_scale(native.FMT_SC8, 1.0 / 32.0)
+    t8 = torch_mod.from_numpy(q).to("cuda:0")
+    whole = fe.process_format_tensor(native.FMT_SC8, t8)
+    assert len(whole) > 100
+    assert fe.process_sharded_tensor(native.FMT_SC8, t8, 5).tobytes() == _clear_head(native, whole).tobytes()
+
+
+def _clear_head(native, recs):
+    r = recs.copy()
+    r["flags"] &= np.uint16(~native.BURST_HEAD & 0xFFFF)
+    return r
+
+
+def test_mid_size_pass_records_arrive_without_a_copy_or_with_one(native, torch_mod):
+    """Round 5: a pass of up to 2^26 samples gets its first 32768 records stored straight into the pinned result buffer by
+    k_compact (beside the device copy); adsb_wait copies only when the pass delivered more.  Both sides of that boundary,
+    blocking and submitted three deep, against the C oracle."""
+    from gr_adsb_amd import modulator as M
+    from gr_adsb_amd.frontend import FrontEnd
+    from oracle import c_oracle as C
+    fs, sps = 2e6, 2
+    n = 1 << 23                                             # 4.2 s: ~3.7 k bursts at 1 k/s; a preamble train keeps one per 128 samples
+    thr = 0.01
+    for bps, lo, hi in ((1000, 2000, 32768), (-32, 32769, 1 << 30)):
+        iq = M.synth_iq(n, fs, bps, seed=5) if bps > 0 else preamble_train_iq(n, spacing=-bps, sps=sps, seed=5)
+        ref = C.process_iq(iq, sps, thr)
+        assert lo <= len(ref) <= hi, len(ref)
+        fe = FrontEnd(fs, thr)
+        t = to_dev(torch_mod, iq)
+        assert_recs_equal(fe.process_iq_tensor(t), ref, "blocking %d" % bps)
+        tickets = [fe.submit_iq_tensor(t) for _ in range(native.MAX_IN_FLIGHT)]
+        for k in tickets:
+            assert_recs_equal(fe.wait(k), ref, "submitted %d" % bps)
+
+
 def test_full_size_properties(native, torch_mod):
     """At the bench size (2^28 samples, generated in HBM) the oracle is too slow to run on everything, so use
     size-independent properties: (1) the whole-buffer result restricted to a window equals the C oracle on
@@ -1134,6 +1216,59 @@ def test_device_side_ordering_after_a_torch_producer(native, torch_mod):
         tk = fe.submit_iq_tensor(dst, 0)
         assert_recs_equal(fe.wait(tk), want, "rep %d" % rep)
     assert_recs_equal(fe.process_iq_tensor(src), want, "blocking entry point")
+
+
+@pytest.mark.parametrize("timing", [False, True])
+def test_device_side_ordering_on_every_slot_stream(native, torch_mod, timing):
+    """Round 5: submitted passes run on one stream per pipeline slot (timed contexts: k_detect on a shared stream), and the
+    caller's event is waited for by the stream the NEXT pass's first kernel runs on.  Three submissions in flight, each with
+    its own late producer on torch's stream; then six events pending in front of ONE submission (more than the context
+    remembers: the oldest are waited for by every queue at once)."""
+    torch = torch_mod
+    from gr_adsb_amd.frontend import FrontEnd
+    from gr_adsb_amd import modulator as M
+    fs, n = 2e6, 1 << 21
+    iqs = [M.synth_iq(n, fs, 3000, seed=90 + k) for k in range(3)]
+    fe = FrontEnd(fs, 0.01, timing=timing)
+    wants = [fe.process_iq(q) for q in iqs]
+    srcs = [to_dev(torch, q) for q in iqs]
+    junk = torch.randn(1 << 24, device="cuda:0")
+    for rep in range(4):
+        dsts, tks = [], []
+        for k in range(3):
+            for _ in range(6):
+                junk = junk * 1.0001 + 0.5
+            d = torch.zeros_like(srcs[k])
+            d.copy_(srcs[k])                             # late producer of THIS submission's input
+            dsts.append(d)
+            tks.append(fe.submit_iq_tensor(d, 0))
+        for k in range(3):
+            assert_recs_equal(fe.wait(tks[k]), wants[k], "rep %d slot %d" % (rep, k))
+    # six producers, six events, one consumer
+    parts = [torch.zeros_like(srcs[0][: n // 6 if i < 5 else n - 5 * (n // 6)]) for i in range(6)]
+    evs = []
+    side = [torch.cuda.Stream() for _ in range(6)]
+    for i, (pt, st) in enumerate(zip(parts, side)):
+        with torch.cuda.stream(st):
+            j = junk * 1.0001
+            for _ in range(4):
+                j = j * 1.0001 + 0.5
+            pt.copy_(srcs[0][i * (n // 6): i * (n // 6) + pt.shape[0]])
+            ev = torch.cuda.Event()
+            ev.record(st)
+            evs.append(ev)
+    whole = torch.empty_like(srcs[0])
+    last = torch.cuda.Stream()
+    with torch.cuda.stream(last):
+        for ev in evs:
+            last.wait_event(ev)
+        torch.cat(parts, out=whole)
+        done = torch.cuda.Event()
+        done.record(last)
+    for ev in evs + [done]:
+        fe.ctx.wait_for_event(ev.cuda_event)
+    got = fe.ctx.wait(fe.ctx.submit_iq_device(whole.data_ptr(), n, 0))
+    assert_recs_equal(got, wants[0], "seven pending events")
 
 
 @pytest.mark.parametrize("n", [6000, 6600])        # pulse inside k_detect's LDS window / longer than it (k_longrun)

@@ -69,3 +69,54 @@ for kind in ("canonical", "shard"):
             kind, log2n, wall / a.reps * 1e6, ts / a.reps * 1e6, tw / a.reps * 1e6, kern, int(nb), n / (wall / a.reps) / 1e9), flush=True)
         ctx.close()
         tctx.close()
+
+# the same passes through the C driver (adsb_process_sharded_device: plan, submit three deep, wait, head fix-up -- no interpreter
+# between two passes): the 2^26-sample stream as 2 .. 64 shards
+print("adsb_process_sharded_device over 2^26 samples: wall per shard, us")
+ctx = _native.Context(a.fs, 0.01)
+out = np.empty(1 << 16, dtype=_native.BURST_DTYPE)
+for shards in (2, 4, 8, 16, 32, 64):
+    for _ in range(3):
+        r = ctx.process_sharded_device(_native.FMT_FC32, iq.data_ptr(), 1 << 26, shards, out=out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 40
+    for _ in range(reps):
+        r = ctx.process_sharded_device(_native.FMT_FC32, iq.data_ptr(), 1 << 26, shards, out=out)
+    wall = (time.perf_counter() - t0) / reps
+    print("shards %3d (2^%.1f samples each)  wall per shard %7.1f   bursts %6d   -> %7.1f Gsamples/s" % (
+        shards, np.log2((1 << 26) / shards), wall / shards * 1e6, len(r), (1 << 26) / wall / 1e9), flush=True)
+ctx.close()
+
+# BASELINE config 4 on one GPU as bench.py runs it: 2^28 samples, 8 shards -- raw context, timed context (two more event
+# records per pass), and through FrontEnd (a torch event + two stream waits per call)
+from gr_adsb_amd.frontend import FrontEnd  # noqa: E402
+big = M.synth_iq_torch(1 << 28, a.fs, 1000, 3, dev)
+torch.cuda.synchronize()
+for name, mk in (("raw context", lambda: _native.Context(a.fs, 0.01)), ("timed context", lambda: _native.Context(a.fs, 0.01, flags=_native.FLAG_TIMING)),
+                 ("FrontEnd, timed", lambda: FrontEnd(a.fs, 0.01, timing=True))):
+    o = mk()
+    call = (lambda: o.process_sharded_tensor(_native.FMT_FC32, big, 8, out=out)) if isinstance(o, FrontEnd) else \
+           (lambda: o.process_sharded_device(_native.FMT_FC32, big.data_ptr(), 1 << 28, 8, out=out))
+    for _ in range(3):
+        r = call()
+    torch.cuda.synchronize()
+    tt = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        for _ in range(4):
+            r = call()
+        torch.cuda.synchronize()
+        tt.append((time.perf_counter() - t0) / 4)
+    w = float(np.median(tt))
+    print("2^28 samples as 8 shards, %-16s %7.1f us per call = %5.1f per shard   bursts %6d   -> %7.1f Gsamples/s" % (
+        name, w * 1e6, w * 1e6 / 8, len(r), (1 << 28) / w / 1e9), flush=True)
+    whole_t = []
+    c2 = o.ctx if isinstance(o, FrontEnd) else o
+    for _ in range(3):
+        c2.process_format_device(_native.FMT_FC32, big.data_ptr(), 1 << 28, 0, fetch=False)
+    for _ in range(6):
+        t0 = time.perf_counter()
+        c2.process_format_device(_native.FMT_FC32, big.data_ptr(), 1 << 28, 0, fetch=False)
+        whole_t.append(time.perf_counter() - t0)
+    print("   the same 2^28 samples as ONE blocking pass: %7.1f us" % (float(np.median(whole_t)) * 1e6), flush=True)

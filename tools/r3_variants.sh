@@ -17,7 +17,7 @@ except Exception:
 for l in open('/tmp/r3v_out.txt'):
     if l.startswith('{'):
         d = json.loads(l); r = d['roofline']
-        print('%-10s %-34s %9.1f Msps  %.4f ms/step  frac %.4f  iso %.4f  sclk %s' % (sys.argv[1], sys.argv[2], d['value'], d['ms_per_step'], r['frac'], r['isolated']['frac'], clk.get('sclk', {}).get('median')))
+        print('%-10s %-34s %9.1f Msps  %.4f ms/step  frac %.4f  iso %.4f  untimed-ctx %s ms/step  sclk %s' % (sys.argv[1], sys.argv[2], d['value'], d['ms_per_step'], r['frac'], r['isolated']['frac'], d.get('timing', {}).get('ms_per_step_untimed_ctx'), clk.get('sclk', {}).get('median')))
 PY
 }
 for cfg in "$@"; do

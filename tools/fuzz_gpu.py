@@ -19,6 +19,10 @@ from oracle import c_oracle as C                # noqa: E402
 from test_sim_property import adversarial_stream  # noqa: E402
 
 
+def want_flags(ctx, x):
+    return ctx.process_mag2(x)["flags"]
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -98,6 +102,25 @@ def run(budget, seed, max_n=None):
             r2 = ctx.wait(t2)
             r2["offset"] -= 77
             assert_recs_equal(r2, want, what + " host-fed #2")
+        if rng.random() < 0.3:                        # device-resident: three submissions in flight (one stream per slot) and
+            import torch                              # the C sharded driver (adsb_process_sharded_device) == the blocking call
+            t = torch.from_numpy(x).to("cuda:0")
+            torch.cuda.synchronize()
+            tk = [ctx.submit_format_device(_native.FMT_MAG2, t.data_ptr(), n, 1000 * k) for k in range(3)]
+            for k, q in enumerate(tk):
+                r = ctx.wait(q)
+                r["offset"] -= 1000 * k
+                assert_recs_equal(r, want, what + " submitted #%d" % k)
+            if n >= 2048:
+                try:
+                    got = ctx.process_sharded_device(_native.FMT_MAG2, t.data_ptr(), n, int(rng.integers(1, 10)))
+                except _native.AdsbError as e:
+                    if e.code != -75:                 # a plateau ran past a shard's halo (-EOVERFLOW): not stitchable
+                        raise
+                    got = None
+                if got is not None:
+                    assert_recs_equal(got, want, what + " sharded in C")
+                    assert np.array_equal(got["flags"] & 0x1FE3, want_flags(ctx, x) & 0x1FE3), what + " sharded flags"
         if n <= 20000 and rng.random() < 0.3:         # fused-path confidence ratios (ADSB_FLAG_CONFIDENCE) vs demod.py:97-101
             cf = cf_ctxs.setdefault(sps, _native.Context(sps * 1e6, thr, flags=_native.FLAG_CONFIDENCE))
             cf.set_threshold(thr)

@@ -38,8 +38,14 @@
 
 namespace adsb {
 
-constexpr int kThreads = 256;            // 4 wavefronts per workgroup
+constexpr int kThreads = 256;            // 4 wavefronts per workgroup: the tail kernels and the one-launch small pass
 constexpr int kWaves = kThreads / 64;
+// k_detect's wavefronts share nothing and meet at no barrier; a workgroup of four only ties four of them together -- the
+// slot of a wavefront that has finished its chunk stays empty until the slowest of its three neighbours has finished too
+// (their burst counts differ), and LDS is handed out four windows at a time.  For the 8-bit formats, which are bound by the
+// instructions their wavefronts issue, k_detect therefore runs ONE wavefront per workgroup (round 5): a slot is refilled
+// the moment its wavefront ends and 21 instead of 20 wavefronts fit on a CU: +6.6 % int8, +6.9 % uint8.  The HBM-bound
+// formats lose 2-5 % that way (complex64, |IQ|^2 floats; int16 +-0) and keep four (profiles/r05_ab_one_wave_workgroups.txt).
 constexpr int kWTile = 1024;             // samples a wavefront owns per tile iteration (16 ballot words)
 constexpr int kFwd = 256;                // forward halo kept in LDS behind every tile
 constexpr int kBack = 128;               // back halo kept in LDS in front of every tile: the <=100-sample noise window (framer.py:156)
@@ -185,6 +191,7 @@ __device__ __forceinline__ float mag2_iq8(unsigned iq, float scale) {
 }
 
 constexpr bool mode_is_iq8(int mode) { return mode == 3 || mode == 4 || mode == 5; }
+constexpr int det_waves(int mode) { return mode_is_iq8(mode) ? 1 : kWaves; }      // wavefronts per k_detect workgroup
 constexpr int mode_bytes(int mode) { return mode == 0 ? 8 : mode_is_iq8(mode) ? 2 : 4; }   // bytes per sample
 
 // One sample as it lies in memory (RawSel<MODE>::type) and its conversion to |IQ|^2, kept apart so that a
@@ -917,17 +924,18 @@ __device__ __forceinline__ bool chips_match(const float* tp, int half_rt) {
 }
 
 // HALF = samples per chip (sps/2) when it is one of the instantiated rates (2, 4, 8, 20 Msps), else 0 = run-time value.
-template <int MODE, int HALF>
+// WPB = wavefronts per workgroup of the kernel this is the body of: 1 for k_detect, kWaves for k_pass_small.
+template <int MODE, int HALF, int WPB = kWaves>
 __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block) {
-  __shared__ __attribute__((aligned(16))) float s_xa[kWaves][kBack + kWWin];
-  __shared__ __attribute__((aligned(16))) unsigned s_ma[kWaves][kMaskDwords];
-  __shared__ __attribute__((aligned(4))) unsigned short s_risea[kWaves][kWTile / 2];
-  __shared__ PendList s_penda[kWaves];
+  __shared__ __attribute__((aligned(16))) float s_xa[WPB][kBack + kWWin];
+  __shared__ __attribute__((aligned(16))) unsigned s_ma[WPB][kMaskDwords];
+  __shared__ __attribute__((aligned(4))) unsigned short s_risea[WPB][kWTile / 2];
+  __shared__ PendList s_penda[WPB];
   // The output stage is for the formats whose tile loop is bound by HBM (complex64, |IQ|^2 floats, int16: +1-5 %); the 8-bit
   // formats are bound by their instruction stream, for which the stage is more instructions (-2 ... -5 %): they keep the
   // store per burst.
   constexpr bool STAGED = !mode_is_iq8(MODE);
-  __shared__ StageBuf s_stagea[STAGED ? kWaves : 1];
+  __shared__ StageBuf s_stagea[STAGED ? WPB : 1];
 
   const int lane = threadIdx.x & 63, wave = adsb_uniform((int)(threadIdx.x >> 6));
   float* s_x = s_xa[wave] + kBack;                           // s_x[j] <-> sample t0 + j, j in [-kBack, kWWin)
@@ -941,7 +949,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
   // instead of living in registers across the tile loop (every k_detect instance spilled 60-90 SGPRs into vector lanes,
   // 8-15 v_readlane reloads per tile).  Hot fields (thr, scale, sps, origin, rec_cap, long_aware) stay by-value.
   auto cold = [&]() { return adsb_cold(a); };
-  const long long unit = (long long)block * kWaves + wave;
+  const long long unit = (long long)block * WPB + wave;
   const long long c0 = unit * cold()->chunk;
   long long c1 = c0 + cold()->chunk;
   if (c1 > cold()->scan_hi) c1 = cold()->scan_hi;
@@ -1276,8 +1284,8 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
   }
 }
 template <int MODE, int HALF>
-__global__ void __launch_bounds__(kThreads, kMinWaves) k_detect(DetectArgs a) {
-  detect_body<MODE, HALF>(a, (int)blockIdx.x);
+__global__ void __launch_bounds__(64 * det_waves(MODE), kMinWaves) k_detect(DetectArgs a) {
+  detect_body<MODE, HALF, det_waves(MODE)>(a, (int)blockIdx.x);
 }
 
 // ---- k_longrun: pulses whose run leaves the LDS window (or starts in the zero history) -------------

@@ -490,11 +490,11 @@ int ensure_pinned(adsb_ctx* c, void*& p, size_t& cap, size_t bytes, bool coheren
 template <int KMODE>
 void launch_detect_k(hipStream_t st, unsigned dyn, const DetectArgs& a, int grid) {
   switch (a.sps) {
-    case 2: hipLaunchKernelGGL((k_detect<KMODE, 1>), dim3(grid), dim3(kThreads), dyn, st, a); break;
-    case 4: hipLaunchKernelGGL((k_detect<KMODE, 2>), dim3(grid), dim3(kThreads), dyn, st, a); break;
-    case 8: hipLaunchKernelGGL((k_detect<KMODE, 4>), dim3(grid), dim3(kThreads), dyn, st, a); break;
-    case 20: hipLaunchKernelGGL((k_detect<KMODE, 10>), dim3(grid), dim3(kThreads), dyn, st, a); break;
-    default: hipLaunchKernelGGL((k_detect<KMODE, 0>), dim3(grid), dim3(kThreads), dyn, st, a); break;
+    case 2: hipLaunchKernelGGL((k_detect<KMODE, 1>), dim3(grid), dim3(64 * det_waves(KMODE)), dyn, st, a); break;
+    case 4: hipLaunchKernelGGL((k_detect<KMODE, 2>), dim3(grid), dim3(64 * det_waves(KMODE)), dyn, st, a); break;
+    case 8: hipLaunchKernelGGL((k_detect<KMODE, 4>), dim3(grid), dim3(64 * det_waves(KMODE)), dyn, st, a); break;
+    case 20: hipLaunchKernelGGL((k_detect<KMODE, 10>), dim3(grid), dim3(64 * det_waves(KMODE)), dyn, st, a); break;
+    default: hipLaunchKernelGGL((k_detect<KMODE, 0>), dim3(grid), dim3(64 * det_waves(KMODE)), dyn, st, a); break;
   }
 }
 // a power of two whose square, times any integer below 2^15, is an exact float32: what the int8 dot-product instance needs
@@ -520,7 +520,7 @@ template <int MODE>
 int detect_occupancy(unsigned dyn) {
   // (the instances of one format differ only in tap addressing: the same resources decide)
   int nb = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_detect<MODE, 0>, kThreads, dyn);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_detect<MODE, 0>, 64 * det_waves(MODE), dyn);
   if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
   return nb;
 }
@@ -636,7 +636,7 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl, bool submitted) {
       s.cs = c->tail_stream;                     // caller-owned compute stream: k_detect there, every tail on the tail stream
     } else {
       s.ds = s.cs = s.stream;
-      // Two kinds of submitted passes keep their k_detect launches one behind the other on a stream of their own (the tail
+      // Three kinds of submitted passes keep their k_detect launches one behind the other on a stream of their own (the tail
       // follows on the slot's stream behind an event -- the arrangement of rounds 2-4):
       //  * timed ones (ADSB_FLAG_TIMING): the HIP events around k_detect are meant to bracket ONE launch that has the
       //    machine to itself -- two launches that overlap share the CUs and each reads twice as long;
@@ -649,8 +649,12 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl, bool submitted) {
       // hardware queues (GPU_MAX_HW_QUEUES), and a k_detect stream that shares its queue with a stream whose tail waits for
       // that k_detect stalls behind it: with a fourth stream for k_detect the timed 2^28-sample legs ran 10 % slower than
       // in round 4 (profiles/r05_pass_cost_timed_with_a_fourth_stream.txt).
+      //  * passes of the 8-bit formats over 1 GiB or more: their one-wavefront workgroups (adsb_device.h) leave no ragged
+      //    end for the next launch to fill, and two instruction-bound launches side by side slow each other down (int8,
+      //    2^30 samples: 0.568 ms in line, 0.607-0.617 overlapped; at 2^28 samples the same either way, below that the
+      //    overlap wins by up to 20 %: profiles/r05_ab_8bit_workgroup_shape_and_schedule.txt).
       const long long in_bytes = (pl.scan_hi > 0 ? pl.scan_hi : 0) * (long long)mode_bytes(pl.mode);
-      if ((c->flags & ADSB_FLAG_TIMING) || in_bytes > (4ll << 30)) {
+      if ((c->flags & ADSB_FLAG_TIMING) || in_bytes > (4ll << 30) || (mode_is_iq8(pl.mode) && in_bytes >= (1ll << 30))) {
         s.ds = c->slot[0].stream;
         s.cs = c->slot[1].stream;
       }
@@ -658,7 +662,7 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl, bool submitted) {
   }
   s.span = pl.scan_hi > 0 ? pl.scan_hi : 0;
   // A "unit" (one wavefront) walks one contiguous chunk and owns one output list.
-  const int upb = kWaves;                                  // units per workgroup
+  const int upb = det_waves(pl.mode);                      // units per k_detect workgroup: four, or one (8-bit formats)
   const int tile = kWTile;
   long long ntiles = (s.span + tile - 1) / tile;
   if (ntiles < 1) ntiles = 1;
@@ -669,8 +673,12 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl, bool submitted) {
   const long long chunk = tiles_per * tile;
   // k_detect keeps pulse centres relative to the start of a unit's chunk in 32 bits
   if (chunk >= (1ll << 30)) return fail(c, -EINVAL, "input too long for one call on this device (chunk per wavefront >= 2^30 samples)");
-  const int grid = (int)((units + upb - 1) / upb);
-  const int nlists = grid * upb;                           // units past `units` own nothing and report empty lists
+  // a call of at most four units of |IQ|^2 floats may run as ONE launch of one four-wavefront workgroup (k_pass_small, below):
+  // it gets four lists whatever it needs (units past `units` own nothing and report empty lists)
+  const bool timing = (c->flags & ADSB_FLAG_TIMING) != 0;
+  const bool can_fuse = units <= kWaves && pl.mode == ADSB_FMT_MAG2 && !timing;
+  const int grid = can_fuse ? 1 : (int)((units + upb - 1) / upb);
+  const int nlists = can_fuse ? kWaves : grid * upb;
   long long rc = (chunk / 256 + 64) << c->rec_cap_shift;
   if (rc > chunk / 2 + 8) rc = chunk / 2 + 8;   // there can never be more rises than that
   rc = (rc + 15) & ~15ll;                       // every list starts on a 128-byte line (k_detect's output stage writes whole lines)
@@ -726,8 +734,7 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl, bool submitted) {
   a.blk_lastp = (long long*)s.d_blk_lastp.p; a.blk_flags = (unsigned*)s.d_blk_flags.p;
   a.longlist = (LongRise*)s.d_long.p; a.long_count = &misc->long_count; a.long_lastp = &misc->long_lastp;
 
-  const bool timing = (c->flags & ADSB_FLAG_TIMING) != 0;
-  s.fused = s.direct && grid == 1 && pl.mode == ADSB_FMT_MAG2 && !timing;
+  s.fused = s.direct && can_fuse;
   // what this pass's first kernel has to wait for: its own upload (host-fed submission), the caller's events (adsb_wait_for_event)
   if (s.h2d_pending) { HIPCHK(c, hipStreamWaitEvent(s.ds, s.h2d_done, 0)); s.h2d_pending = false; }
   { int r_ = apply_ext(c, s.ds); if (r_) return r_; }

@@ -118,7 +118,7 @@ typedef struct adsb_stats {
   uint64_t retries;          /* record-capacity regrowths */
   uint64_t longrun_calls;    /* calls that needed the long-pulse kernel */
   uint64_t detect_grid;      /* workgroups of the last k_detect launch */
-  uint64_t blocks_per_cu;    /* resident k_detect workgroups per CU (occupancy query) */
+  uint64_t blocks_per_cu;    /* resident k_detect workgroups per CU (occupancy query): four wavefronts each, one for the 8-bit formats */
   double detect_gap_ms;      /* sum of idle gaps on the compute stream between consecutive timed k_detect launches */
   uint64_t detect_gaps;      /* number of gaps summed */
   uint64_t longrun_pulses;   /* pulses longer than k_detect's LDS window, handled by the long-pulse kernel (sum over calls) */
@@ -323,7 +323,7 @@ float adsb_snr_db(float peak, float median);
 uint32_t adsb_mode_s_syndrome(const uint8_t bits[14], int32_t* df, int32_t* nbits);
 
 /* How one call over n_samples is cut on a device that keeps `resident_wavefronts` wavefronts of the streaming kernel
- * resident (adsb_stats.detect_grid / blocks_per_cu tell what a context uses: CUs x blocks_per_cu x 4): *units chunks of
+ * resident (adsb_stats.detect_grid / blocks_per_cu tell what a context uses: CUs x blocks_per_cu x 4, or x 1 for the 8-bit formats): *units chunks of
  * *samples_per_chunk samples each (the last may be shorter), one wavefront and one output list per chunk.  One resident
  * round is the floor; a bulk call runs up to eight rounds of shorter chunks (never shorter than 4096 samples) so that the
  * dispatcher evens out wavefronts that finish apart.  Pure host arithmetic (no device needed), the reference has no

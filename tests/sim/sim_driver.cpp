@@ -40,15 +40,18 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
             unsigned long long* out_recs /* 4 words each */, int out_cap, SimOut* so) {
   // same unit geometry as adsb_hip.hip: enqueue()  (grid_max = resident workgroups available)
   const long long span = scan_hi > 0 ? scan_hi : 0;
-  const int upb = kWaves;
+  const int upb = det_waves(mode);          // wavefronts per k_detect workgroup: four, or one (8-bit formats)
   const int tile = kWTile;
   long long ntiles = (span + tile - 1) / tile;
   if (ntiles < 1) ntiles = 1;
   long long units = 0, tiles_per = 0;
-  plan_chunks(ntiles, (long long)grid_max * upb, &units, &tiles_per);     // adsb_plan.h: the library's own chunk / round policy
+  plan_chunks(ntiles, (long long)grid_max * kWaves, &units, &tiles_per);  // adsb_plan.h: the library's own chunk / round policy
   const long long chunk = tiles_per * tile;
-  const int grid = (int)((units + upb - 1) / upb);
-  const int nlists = grid * upb;
+  // like adsb_hip.hip: enqueue(): k_detect runs one wavefront per workgroup (grid = units); a call of at most four units of
+  // |IQ|^2 floats gets the four lists of the one-launch small pass
+  const bool can_fuse = units <= kWaves && mode == 1;
+  const int grid = can_fuse ? 1 : (int)((units + upb - 1) / upb);
+  const int nlists = can_fuse ? kWaves : grid * upb;
   const int rec_cap = rec_cap_in > 0 ? rec_cap_in : (int)(chunk / 2 + 8);
   const long long tot = (long long)nlists * rec_cap;
 
@@ -79,15 +82,15 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
 
   // same choice as adsb_hip.hip: enqueue(): a one-workgroup pass over |IQ|^2 floats whose tail is the fused one runs as ONE
   // kernel, k_pass_small (g_tail_mode 1 = always the kernel chain)
-  const bool one_launch = mode == 1 && grid == 1 && (g_tail_mode == 2 || (g_tail_mode == 0 && tot <= 16384));
+  const bool one_launch = can_fuse && (g_tail_mode == 2 || (g_tail_mode == 0 && tot <= 16384));
   // the instance the library would launch (per format and samples per chip), like adsb_hip.hip: launch_detect()
 #define SIM_DETECT(MODE)                                                                   \
   switch (sps) {                                                                           \
-    case 2: hipsim::launch(k_detect<MODE, 1>, grid, kThreads, a); break;                   \
-    case 4: hipsim::launch(k_detect<MODE, 2>, grid, kThreads, a); break;                   \
-    case 8: hipsim::launch(k_detect<MODE, 4>, grid, kThreads, a); break;                   \
-    case 20: hipsim::launch(k_detect<MODE, 10>, grid, kThreads, a); break;                 \
-    default: hipsim::launch(k_detect<MODE, 0>, grid, kThreads, a); break;                  \
+    case 2: hipsim::launch(k_detect<MODE, 1>, grid, 64 * det_waves(MODE), a); break;       \
+    case 4: hipsim::launch(k_detect<MODE, 2>, grid, 64 * det_waves(MODE), a); break;       \
+    case 8: hipsim::launch(k_detect<MODE, 4>, grid, 64 * det_waves(MODE), a); break;       \
+    case 20: hipsim::launch(k_detect<MODE, 10>, grid, 64 * det_waves(MODE), a); break;     \
+    default: hipsim::launch(k_detect<MODE, 0>, grid, 64 * det_waves(MODE), a); break;      \
   }
   // like adsb_hip.hip: launch_detect(): int8 IQ with a power-of-two scale runs the dot-product instance
   int fe = 0;

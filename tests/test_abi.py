@@ -178,27 +178,32 @@ def test_head_sync_predicts_fixup_and_fixup_is_exact(native):
 
 
 def test_kernel_resources_keep_the_tail_co_resident():
-    """The pipelined pass rate depends on a resource fact, not only on code: k_detect keeps five workgroups resident per CU
-    (in one to eight rounds), and the sparse tail kernels of the PREVIOUS pass run beside them.  If they do not fit in
-    what five k_detect workgroups leave free on a CU, they run when k_detect drains and the next k_detect starts with
-    some of its workgroups in a second round (measured: 1.89 instead of 1.51 ms per pass when k_detect took 96 VGPRs).
-    The compiler's own report (written by gr_adsb_amd.build) is checked against those limits here."""
+    """The pipelined pass rate depends on a resource fact, not only on code: k_detect fills a CU with resident wavefronts
+    -- five workgroups of four (complex64, |IQ|^2 floats, int16), or 21 workgroups of one (the 8-bit formats, round 5: six
+    1280-byte LDS granules per wavefront) -- and the sparse tail kernels of the PREVIOUS pass run beside them.  If they do not
+    fit in what those leave free, they run when k_detect drains and the next k_detect starts with some of its workgroups in
+    a second round (measured in round 2: 1.89 instead of 1.51 ms per pass when k_detect took 96 VGPRs).  The compiler's own
+    report (written by gr_adsb_amd.build) is checked against those limits here."""
     import json
     from gr_adsb_amd import build as B
     B.build()
     res = json.load(open(B.RES))
-    LDS_CU, VGPR_SIMD, WG = 160 * 1024, 512, 5
+    LDS_CU, VGPR_SIMD, SIMDS, GRAN = 160 * 1024, 512, 4, 1280
     alloc = lambda v: -(-v // 8) * 8                                    # noqa: E731  (allocation granule: 8 VGPRs)
+    gran = lambda b: -(-b // GRAN) * GRAN                               # noqa: E731  (LDS allocation granule on gfx950)
     detect = {k: v for k, v in res.items() if "k_detect" in k}
     assert len(detect) == 30            # (5 input formats + int8 with a power-of-two scale) x 5 samples-per-chip instances
     tail = {k: v for k, v in res.items() if any(t in k for t in ("k_order", "k_resolve", "k_count", "k_compact"))}
     assert len(tail) == 8                                               # k_order per input format + three format-blind kernels
     for name, d in detect.items():
         assert d["scratch_bytes_per_lane"] == 0 and d["vgpr_spills"] == 0, name + ": spills in the streaming kernel"
-        assert d["occupancy_waves_per_simd"] >= WG, name
-        free_vgpr = VGPR_SIMD - WG * alloc(d["vgprs"])
-        gran = lambda b: -(-b // 1280) * 1280                           # noqa: E731  (LDS allocation granule on gfx950)
-        free_lds = LDS_CU - WG * gran(d["lds_bytes_per_block"])
+        mode = int(re.search(r"k_detectILi(\d)E", name).group(1))
+        wpb = 1 if mode in (3, 4, 5) else 4                             # adsb_device.h: det_waves
+        wg_cu = min(LDS_CU // gran(d["lds_bytes_per_block"]), SIMDS * (VGPR_SIMD // alloc(d["vgprs"])) // wpb, 32)
+        assert wg_cu == (21 if wpb == 1 else 5), (name, wg_cu)
+        free_lds = LDS_CU - wg_cu * gran(d["lds_bytes_per_block"])
+        # wavefronts on the fullest SIMD: five of a workgroup of four each; 21 single ones = 6 + 5 + 5 + 5
+        free_vgpr = VGPR_SIMD - (6 if wpb == 1 else 5) * alloc(d["vgprs"])
         for tname, t in tail.items():
             assert alloc(t["vgprs"]) <= free_vgpr, "%s (%d VGPRs) does not fit beside %s (%d)" % (tname, t["vgprs"], name, d["vgprs"])
             assert gran(t["lds_bytes_per_block"]) <= free_lds, "%s (%d B LDS) does not fit beside %s" % (tname, t["lds_bytes_per_block"], name)

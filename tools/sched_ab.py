@@ -55,7 +55,11 @@ mag = (iq * iq).sum(dim=1).contiguous()
 run("2 Msps |IQ|^2 2^30", _native.FMT_MAG2, mag, 1 << 30, 2e6)
 del mag
 q8 = torch.clamp(torch.round(iq * (128.0 / 4.0)), -127, 127).to(torch.int8).contiguous()
-run("2 Msps int8 2^30", _native.FMT_SC8, q8, 1 << 30, 2e6, scale=4.0 / 128.0)
+for lg in (30, 28, 26, 24, 22):
+    run("2 Msps int8 2^%d" % lg, _native.FMT_SC8, q8, 1 << lg, 2e6, scale=4.0 / 128.0, steps=20 if lg >= 26 else 100)
+u8 = (q8.to(torch.int16) + 128).to(torch.uint8).contiguous()
+run("2 Msps uint8 2^30", _native.FMT_CU8, u8, 1 << 30, 2e6, scale=4.0 / 255.0)
+del u8
 del q8, iq
 torch.cuda.empty_cache()
 iq = stream(8e6, 6000, 28, 2)

@@ -219,3 +219,29 @@ def preamble_train_iq(n, spacing=32, sps=2, seed=3):
     iq.real = a
     iq.imag = (rng.random(n, dtype=np.float32) * np.float32(0.01)).astype(np.float32)
     return iq
+
+
+def rise_storm_iq8(n, seed=0, offset_binary=False, hi=100, lo=2):
+    """Interleaved 8-bit IQ (2n values) whose |IQ|^2 crosses a threshold of 0.01 (scale 1/128) up to 512 times per 1024-sample
+    tile: 16-sample blocks that are either alternating high / low (8 rises), a bare preamble pattern at half-chip spacing 1
+    (chips 0, 2, 7, 9 high: 4 rises, the first one a matched centre at 2 Msps) or quiet -- more rises per tile than the 8-bit
+    formats' rise list holds (256), with matched preambles in every part of the tile, so the batches of k_detect's B.1 loop
+    are exercised and their hits must come out in stream order."""
+    rng = np.random.default_rng(seed)
+    nb = n // 16
+    kind = rng.choice(3, size=nb, p=[0.6, 0.3, 0.1])
+    i = np.full(n, lo, dtype=np.int16)
+    alt = np.zeros(16, dtype=np.int16)
+    alt[0::2] = hi - lo
+    pre = np.zeros(16, dtype=np.int16)
+    pre[[0, 2, 7, 9]] = hi - lo
+    blocks = i[:nb * 16].reshape(nb, 16)
+    blocks[kind == 0] += alt
+    blocks[kind == 1] += pre
+    blocks += rng.integers(0, 3, size=blocks.shape, dtype=np.int16) * (blocks > lo)        # unequal peaks: medians / SNR vary
+    q = np.zeros(2 * n, dtype=np.int16)
+    q[0::2] = i
+    q[1::2] = rng.integers(-1, 2, size=n)
+    if offset_binary:
+        return ((q + 255) // 2).clip(0, 255).astype(np.uint8)       # (2u - 255) ~ q: odd integers, same pattern
+    return q.astype(np.int8)

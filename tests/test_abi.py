@@ -200,14 +200,19 @@ def test_kernel_resources_keep_the_tail_co_resident():
         mode = int(re.search(r"k_detectILi(\d)E", name).group(1))
         wpb = 1 if mode in (3, 4, 5) else 4                             # adsb_device.h: det_waves
         wg_cu = min(LDS_CU // gran(d["lds_bytes_per_block"]), SIMDS * (VGPR_SIMD // alloc(d["vgprs"])) // wpb, 32)
-        assert wg_cu == (21 if wpb == 1 else 5), (name, wg_cu)
+        assert wg_cu == (21 if wpb == 1 else 5), (name, wg_cu)            # 8-bit: six LDS granules per wavefront
         free_lds = LDS_CU - wg_cu * gran(d["lds_bytes_per_block"])
-        # wavefronts on the fullest SIMD: five of a workgroup of four each; 21 single ones = 6 + 5 + 5 + 5
-        free_vgpr = VGPR_SIMD - (6 if wpb == 1 else 5) * alloc(d["vgprs"])
+        # resident k_detect wavefronts per SIMD: five of a workgroup of four each; 21 single ones = 6 + 5 + 5 + 5
+        per_simd = [6, 5, 5, 5] if wpb == 1 else [5, 5, 5, 5]
         for tname, t in tail.items():
-            assert alloc(t["vgprs"]) <= free_vgpr, "%s (%d VGPRs) does not fit beside %s (%d)" % (tname, t["vgprs"], name, d["vgprs"])
             assert gran(t["lds_bytes_per_block"]) <= free_lds, "%s (%d B LDS) does not fit beside %s" % (tname, t["lds_bytes_per_block"], name)
             assert t["scratch_bytes_per_lane"] == 0, tname
+            # the four wavefronts of a tail workgroup need register room somewhere on the CU.  (k_order is the exception by
+            # design: it is launched with 8 KB of unused dynamic LDS so that it starts when k_detect drains -- adsb_hip.hip:
+            # enqueue_tail -- and the kernels behind it follow in stream order)
+            slots = sum((VGPR_SIMD - w * alloc(d["vgprs"])) // alloc(t["vgprs"]) for w in per_simd)
+            if "k_order" not in tname:
+                assert slots >= 4, "%s (%d VGPRs) does not fit beside %s (%d)" % (tname, t["vgprs"], name, d["vgprs"])
 
 
 def test_chunk_plan_covers_the_call_and_keeps_its_limits(native):

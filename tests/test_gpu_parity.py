@@ -231,6 +231,33 @@ def test_canonical_int16_iq_matches_reference_goldens(native, torch_mod, name):
     assert_recs_match_golden(ctx.wait(tk), g)
 
 
+@pytest.mark.parametrize("fmt_name,scale", [("sc8", 1.0 / 128.0), ("sc8", 1.0 / 127.0), ("cu8", 1.0 / 255.0)])
+@pytest.mark.parametrize("fs", [2e6, 8e6, 6e6])
+def test_every_rise_a_tile_can_have_8bit_formats(native, torch_mod, fmt_name, scale, fs):
+    """Up to 512 rises per 1024-sample tile -- every rise a tile can have -- with matched preambles all over them, through the
+    8-bit formats (one wavefront per k_detect workgroup since round 5; the test was written for a variant whose rise list held
+    256 of them and worked a tile off in batches: profiles/r05_ab_25_waves_8bit_rejected.txt): 2^20 samples, blocking and as
+    three submissions in flight, against the C oracle on the oracle's conversion of the same bytes."""
+    from helpers import rise_storm_iq8
+    from oracle import adsb_oracle as O
+    from oracle import c_oracle as C
+    fmt = native.FMT_SC8 if fmt_name == "sc8" else native.FMT_CU8
+    n, sps = (1 << 20) + 77, int(fs // 1e6)
+    q = rise_storm_iq8(n, seed=int(fs // 1e6), offset_binary=fmt_name == "cu8")
+    x = O.mag2_iq8(q, float(np.float32(scale)), fmt_name == "cu8")
+    want = C.canonical(x, sps, np.float32(0.01))
+    assert len(want) > (2000 if sps == 2 else 0)
+    ctx = native.Context(fs, 0.01)
+    ctx.set_format_scale(fmt, scale)
+    assert_recs_equal(ctx.process_format(fmt, q), want, "rise storm %s %g %g" % (fmt_name, scale, fs))
+    t = torch_mod.from_numpy(q.reshape(-1, 2)).to("cuda:0")
+    torch_mod.cuda.synchronize()
+    tk = [ctx.submit_format_device(fmt, t.data_ptr(), n, 0) for _ in range(3)]
+    for k in tk:
+        assert_recs_equal(ctx.wait(k), want, "rise storm, submitted")
+    ctx.close()
+
+
 @pytest.mark.parametrize("fs,bps", [(2e6, 2000), (8e6, 6000), (20e6, 2000)])
 @pytest.mark.parametrize("fmt", ["sc8", "cu8"])
 def test_int8_iq_formats_vs_c_oracle(native, torch_mod, fs, bps, fmt):

@@ -562,3 +562,34 @@ def test_signed_zeros_in_the_noise_window_match_the_reference(name):
         recs = np.concatenate(outs)
         assert np.array_equal(recs["offset"], g.get("random", "tag_offsets"))
         assert np.array_equal(snr_bits(recs["peak"], recs["median"]), g.get("random", "tag_snr_bits"))
+
+
+@pytest.mark.parametrize("mode,scale", [(3, 1.0 / 128.0), (3, 1.0 / 127.0), (4, 1.0 / 255.0)])
+@pytest.mark.parametrize("fs", [2e6, 4e6, 6e6])
+def test_every_rise_a_tile_can_have_8bit_formats(mode, scale, fs):
+    """Streams with up to 512 rises per tile -- every rise a tile can have -- and matched preambles all over them, through the
+    8-bit formats: the dot-product instance (scale 2^-7), the generic int8 one and uint8, a compiled-in tap stride and a
+    run-time one.  (Written for a rejected variant whose rise list held 256 rises and worked a tile off in batches; the
+    bursts behind the 256th rise of a tile are what that variant's second batch had to deliver.)"""
+    from helpers import rise_storm_iq8
+    sps = int(fs // 1e6)
+    for seed, n in ((1, 1024 * 7 + 300), (2, 1024 * 3)):
+        q = rise_storm_iq8(n, seed=seed, offset_binary=mode == 4)
+        x = O.mag2_iq8(q, float(np.float32(scale)), mode == 4)
+        above = x >= np.float32(0.01)
+        rises = above[1:] & ~above[:-1]
+        per_tile = [int(rises[t:t + 1024].sum()) for t in range(0, n - 1, 1024)]
+        assert max(per_tile) > 300, per_tile
+        want = C.canonical(x, sps, np.float32(0.01))
+        recs, so = simlib.sim_canonical(mode, q, fs, 0.01, scale=float(np.float32(scale)))
+        assert_recs_equal(recs, want, "rise storm mode %d scale %g fs %g seed %d" % (mode, scale, fs, seed))
+        if sps == 2:
+            assert len(want) > 10
+            # ... and some delivered bursts are rises number 256 and up of their tile (tiles start at the first framer sample,
+            # -(8*sps - 1)): they come out of the second batch
+            ridx = np.flatnonzero(rises) + 1
+            late = 0
+            for off in want["offset"]:
+                t0 = -(8 * sps - 1) + ((int(off) + 8 * sps - 1) // 1024) * 1024
+                late += int(np.count_nonzero((ridx >= t0) & (ridx < off)) >= 256)
+            assert late >= 1, "no burst behind the 256th rise of a tile"

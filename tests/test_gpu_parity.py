@@ -246,7 +246,8 @@ def test_every_rise_a_tile_can_have_8bit_formats(native, torch_mod, fmt_name, sc
     q = rise_storm_iq8(n, seed=int(fs // 1e6), offset_binary=fmt_name == "cu8")
     x = O.mag2_iq8(q, float(np.float32(scale)), fmt_name == "cu8")
     want = C.canonical(x, sps, np.float32(0.01))
-    assert len(want) > (2000 if sps == 2 else 0)
+    if sps == 2:                                   # (the blocks' bare preambles are spaced for 2 Msps; at other rates: rises only)
+        assert len(want) > 2000
     ctx = native.Context(fs, 0.01)
     ctx.set_format_scale(fmt, scale)
     assert_recs_equal(ctx.process_format(fmt, q), want, "rise storm %s %g %g" % (fmt_name, scale, fs))

@@ -644,15 +644,15 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl, bool submitted) {
       //    and two HBM-bound launches that run side by side cost about that in DRAM locality (complex64, 2^30 samples:
       //    1.354-1.372 ms chained, 1.375-1.377 overlapped).  Everything smaller gains from the overlap: 2^28 samples +4-5 %,
       //    2^26 +20 %, 2^24 +38 %; the instruction-bound formats +2-6 % at any size (profiles/r05_ab_queue_arrangements.txt).
+      //  * passes of the 8-bit formats over 1 GiB or more: their one-wavefront workgroups (adsb_device.h) leave no ragged
+      //    end for the next launch to fill, and two instruction-bound launches side by side slow each other down (int8,
+      //    2^30 samples: 0.568 ms in line, 0.607-0.617 overlapped; at 2^28 samples the same either way, below that the
+      //    overlap wins by up to 20 %: profiles/r05_ab_8bit_workgroup_shape_and_schedule.txt).
       // No stream is added for that: the three slot streams take the three roles -- slot 0's every k_detect, slot 1's every
       // tail, slot 2's the record copies (finish) -- because the runtime multiplexes all streams of a process onto FOUR
       // hardware queues (GPU_MAX_HW_QUEUES), and a k_detect stream that shares its queue with a stream whose tail waits for
       // that k_detect stalls behind it: with a fourth stream for k_detect the timed 2^28-sample legs ran 10 % slower than
       // in round 4 (profiles/r05_pass_cost_timed_with_a_fourth_stream.txt).
-      //  * passes of the 8-bit formats over 1 GiB or more: their one-wavefront workgroups (adsb_device.h) leave no ragged
-      //    end for the next launch to fill, and two instruction-bound launches side by side slow each other down (int8,
-      //    2^30 samples: 0.568 ms in line, 0.607-0.617 overlapped; at 2^28 samples the same either way, below that the
-      //    overlap wins by up to 20 %: profiles/r05_ab_8bit_workgroup_shape_and_schedule.txt).
       const long long in_bytes = (pl.scan_hi > 0 ? pl.scan_hi : 0) * (long long)mode_bytes(pl.mode);
       if ((c->flags & ADSB_FLAG_TIMING) || in_bytes > (4ll << 30) || (mode_is_iq8(pl.mode) && in_bytes >= (1ll << 30))) {
         s.ds = c->slot[0].stream;

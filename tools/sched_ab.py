@@ -1,5 +1,7 @@
-"""Wall time per pipelined pass (three in flight, context WITHOUT ADSB_FLAG_TIMING) for a list of workloads: the figure the
-choice of the stream arrangement is made on (round 5).  One process per arrangement while the experiment lasts.
+"""Wall time per pipelined pass (three in flight, context WITHOUT ADSB_FLAG_TIMING: the product default) for a list of
+workloads and pass sizes.  Round 5 chose the stream arrangement and the 8-bit formats' workgroup shape with it: one process
+per variant (ADSB_HIP_LIB = a side copy built by tools/kbench.py), results in profiles/r05_ab_queue_arrangements.txt,
+r05_ab_8bit_workgroup_shape_and_schedule.txt, r05_ab_workgroup_shape_by_size_fc32.txt.
     python tools/sched_ab.py [tag]            (GPU box only)"""
 import os
 import sys

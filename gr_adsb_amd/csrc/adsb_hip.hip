@@ -830,7 +830,10 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
     const Rec* recs_dev = (const Rec*)(s.direct ? s.h_out : s.d_out.p);
     if (nres > 0 && (!in_host || (c->flags & ADSB_FLAG_CONFIDENCE))) {
       // on the pass's own stream (idle: its last kernel has completed); never on a caller-owned one
-      const hipStream_t xs = !c->own_stream ? c->copy_stream : (s.ds != s.cs ? c->slot[2].stream : s.cs);
+      // (a submitted pass that shares its stream with the passes behind it -- kernels in line, or ADSB_FLAG_SINGLE_STREAM --
+      // copies on slot 2's stream: on its own one the copy would wait for everything queued since)
+      const bool shared = s.ds != s.cs || (s.submitted && !c->split_tail);
+      const hipStream_t xs = !c->own_stream ? c->copy_stream : (shared ? c->slot[2].stream : s.cs);
       if (!in_host)
         FINCHK(hipMemcpyAsync(s.h_out, s.d_out.p, (size_t)nres * sizeof(Rec), hipMemcpyDeviceToHost, xs));
       if (c->flags & ADSB_FLAG_CONFIDENCE) {

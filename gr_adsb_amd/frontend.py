@@ -37,10 +37,15 @@ def _after_torch(ctx, t):
     (adsb_set_stream / FrontEnd.use_torch_stream is the alternative: share torch's stream and skip this.)"""
     import torch
     assert t.is_cuda and t.is_contiguous()
-    ev = torch.cuda.Event()
+    # a ring of eight re-recordable events per context: the wait is queued with the NEXT call on the context (which follows
+    # at once), so an event is long done with by the time its turn comes again -- and none is created per call
+    ring = getattr(ctx, "_torch_events", None)
+    if ring is None:
+        ring = ctx._torch_events = [[torch.cuda.Event() for _ in range(8)], 0]
+    ev = ring[0][ring[1] & 7]
+    ring[1] += 1
     ev.record(torch.cuda.current_stream(t.device))
     ctx.wait_for_event(ev.cuda_event)
-    ctx._torch_events = (getattr(ctx, "_torch_events", []) + [ev])[-8:]      # alive until the dependency has been queued
 
 
 class FrontEnd:

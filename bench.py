@@ -561,7 +561,7 @@ class ShardedRun:
 
 
 def sharded_leg(args, dev, rank, n_gpus, fs, bursts, seed, n_own, steps, warmup, min_time, depth, sync_all, reduce_max,
-                ag_int, ag_obj, synth, fe=None, extra_me=None):
+                ag_int, ag_obj, synth, fe=None, extra_me=None, untimed=False):
     """One stream of n_own * n_gpus samples tiled as n_gpus overlapped time shards, one per rank; returns this rank's view
     (every rank gets the same dict: times are max over ranks, per_rank and the seam check are gathered)."""
     import torch
@@ -602,10 +602,26 @@ def sharded_leg(args, dev, rank, n_gpus, fs, bursts, seed, n_own, steps, warmup,
           "numa_node": numa["node"], "local_cpulist": numa["cpulist"]}
     me.update(extra_me or {})
     per_rank = ag_obj(me)
+    prod = None
+    if untimed:
+        # the same leg on contexts of the product's default kind (no ADSB_FLAG_TIMING: the ranks' passes free to overlap on one
+        # stream per pipeline slot; the timed contexts above keep their k_detect launches in line so that every event pair
+        # brackets one launch) -- a wall time only, three repeats, every rank takes part (the exchange is collective)
+        fe2 = FrontEnd(fs, args.threshold, device=dev.index, timing=False)
+        run2 = ShardedRun(fe2, iq, plan, stream_len, sps, rank, ag_int, ag_obj, depth)
+        for _ in range(warmup):
+            run2.step()
+        run2.drain()
+        t2, _ = timed_repeats(run2.step, run2.drain, sync_all, reduce_max, steps, 0.0, max_repeats=3)
+        e2 = float(np.median(t2))
+        prod = {"ms_per_step": round(e2 / steps * 1e3, 4), "value": round(float(stream_len) * steps / e2 / 1e6, 1),
+                "unit": "Msamples/s", "repeats": len(t2),
+                "note": "same shards on contexts without ADSB_FLAG_TIMING (the product default: passes overlap)"}
+        fe2.ctx.close()
     seam = seam_check(args, fe, dev, rank, n_gpus, sps, n_own, stream_len, run.last_kept, ag_obj, fs=fs, bursts=bursts,
                       seed=seed, synth=synth)
     elapsed = float(np.median(times))
-    return {"fs": fs, "n_own": n_own, "stream_len": stream_len, "times": times, "elapsed": elapsed, "stats": st,
+    return {"fs": fs, "n_own": n_own, "stream_len": stream_len, "times": times, "elapsed": elapsed, "stats": st, "product_default": prod,
             "value": round(float(stream_len) * steps / elapsed / 1e6, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
             "n_bursts": int(n_bursts), "per_rank": per_rank, "seam": seam, "fe": fe, "iq": iq}
 
@@ -621,13 +637,13 @@ def config4_legs(args, dev, rank, n_gpus, depth, sync_all, reduce_max, ag_int, a
     fe = None
     for name, n_own in (("weak", 1 << args.log2n), ("strong", max(1 << 22, (1 << args.log2n) // n_gpus))):
         leg = sharded_leg(args, dev, rank, n_gpus, 20e6, 1000.0, 3, n_own, args.extra_steps, 3, args.extra_min_time, depth,
-                          sync_all, reduce_max, ag_int, ag_obj, {}, fe=fe)
+                          sync_all, reduce_max, ag_int, ag_obj, {}, fe=fe, untimed=True)
         fe = leg["fe"]
         out[name] = {"scaling": name, "samples_per_gpu_per_step": n_own, "stream_samples_per_step": leg["stream_len"],
                      "value": leg["value"], "unit": "Msamples/s", "ms_per_step": leg["ms_per_step"], "steps": args.extra_steps,
                      "repeats": len(leg["times"]), "bursts_per_step_rank0": leg["n_bursts"],
                      "hbm_frac_whole_job": round(8.0 * leg["stream_len"] / (leg["ms_per_step"] * 1e-3) / 1e9 / (HBM_PEAK_GBS * n_gpus), 4),
-                     "per_rank": leg["per_rank"], "seam_check": leg["seam"],
+                     "per_rank": leg["per_rank"], "seam_check": leg["seam"], "product_default": leg["product_default"],
                      "stitch_fallbacks_total": int(sum(r["stitch_fallbacks"] for r in leg["per_rank"]))}
         del leg
         torch.cuda.empty_cache()
@@ -1006,6 +1022,8 @@ def main():
                 for leg_name in ("weak", "strong"):
                     cfgd["cfg4_%s_msps" % leg_name] = cfg4[leg_name]["value"]
                     cfgd["cfg4_%s_ms" % leg_name] = cfg4[leg_name]["ms_per_step"]
+                    if cfg4[leg_name].get("product_default"):
+                        cfgd["cfg4_%s_ms_untimed_ctx" % leg_name] = cfg4[leg_name]["product_default"]["ms_per_step"]
                     cfgd["cfg4_%s_seams_identical" % leg_name] = bool(cfg4[leg_name]["seam_check"]["all_identical"])
                     cfgd["cfg4_%s_per_rank_frac" % leg_name] = [r_["roofline_frac"] for r_ in cfg4[leg_name]["per_rank"]]
         print(json.dumps(result), flush=True)

@@ -101,6 +101,32 @@ int main(int argc, char** argv) {
     }
     free(got2);
   }
+  /* ABI 4: the stream as overlapped time shards, planned, pipelined and stitched inside the library (one C call).  The
+   * page-locked buffer is device-visible under its host address (hipHostMalloc), so it serves as the "device" input here:
+   * 1, 3 and 7 shards, each identical to the blocking result; the tiling itself (adsb_shard_bounds) covers the stream. */
+  if (n >= 4096) {
+    adsb_burst* got3 = (adsb_burst*)calloc((size_t)nwant + 1, sizeof(adsb_burst));
+    const int32_t shard_counts[3] = {1, 3, 7};
+    for (int k = 0; k < 3 && !bad; ++k) {
+      int32_t m = -1;
+      const int32_t S = shard_counts[k];
+      if (adsb_process_sharded_device(c, ADSB_FMT_FC32, pinned, n, 0, S, got3, nwant + 1, &m) != 0 || m != nwant) { bad = 1; break; }
+      for (int32_t i = 0; i < nwant && !bad; ++i)
+        bad = got3[i].offset != got[i].offset || memcmp(got3[i].bits, got[i].bits, 14) || memcmp(&got3[i].peak, &got[i].peak, 8) ||
+              ((got3[i].flags ^ got[i].flags) & (uint16_t)~ADSB_BURST_HEAD);
+      int64_t prev_hi = 0;
+      for (int32_t g = 0; g < S && !bad; ++g) {
+        int64_t olo = -1, ohi = -1, lo = -1, hi = -1;
+        if (adsb_shard_bounds(n, S, g, (int)(fs / 1e6), 4096, &olo, &ohi, &lo, &hi) != 0 || olo != prev_hi || lo > olo || hi < ohi || (lo & 3)) bad = 1;
+        prev_hi = ohi;
+      }
+      if (!bad && prev_hi != n) bad = 1;
+    }
+    int32_t m0 = -1;
+    if (!bad && nwant > 1 && (adsb_process_sharded_device(c, ADSB_FMT_FC32, pinned, n, 0, 3, got3, 1, &m0) != -ENOSPC || m0 != nwant)) bad = 1;
+    if (!bad && adsb_process_sharded_device(c, ADSB_FMT_FC32, pinned, n, 0, 0, got3, nwant + 1, &m0) != -EINVAL) bad = 1;
+    free(got3);
+  }
   /* opt-in confidence ratios (demod.py:97-101): a context without the flag refuses, one with it returns n x 112 floats
    * whose sign test reproduces the hard bits (bit = bit1_amp > bit0_amp  <=>  ratio > 1 for positive amplitudes) */
   {

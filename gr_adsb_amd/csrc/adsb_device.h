@@ -1164,6 +1164,11 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
       keepp = (adsb_readlane((int)W, 63) >> 15) & 1;
       uflags |= (anyr ? 1u : 0u) | (anyf ? 2u : 0u);
       if (anyr) {                                            // wave-uniform
+        // The wavefront that has met rises runs its per-rise / per-record chain at raised issue priority (s_setprio) and drops
+        // back when the tile's records are done: its SIMD neighbours are mostly streaming quiet tiles and lose nothing
+        // measurable -- uint8 +3.5 %, int8 +1.1 %, int16 +0.6 %, |IQ|^2 floats +0.2 %, complex64 0
+        // (profiles/r05_ab_wave_priority_cu8.txt, r05_ab_wave_priority_all.txt)
+        adsb_setprio<3>();
         // Ordered rise list: the slots of a lane follow from the prefix sum of the per-lane counts; every lane then
         // stores the positions of its (at most 8) rises in a short loop.
         const unsigned cnt = (unsigned)__builtin_popcount(piece);
@@ -1182,6 +1187,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
         const bool easy = it >= it_e0 && it < it_e1;
         if (easy) rises_to_records(BoolC<true>{}, it, t0, nr, lane);
         else rises_to_records(BoolC<false>{}, it, t0, nr, lane);
+        adsb_setprio<0>();
       }
     }
 

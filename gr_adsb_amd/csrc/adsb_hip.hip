@@ -53,6 +53,9 @@ __device__ __forceinline__ Q adsb_ld_stream(const char* p) {
   using V = float __attribute__((ext_vector_type(sizeof(Q) / 4)));
   return __builtin_bit_cast(Q, __builtin_nontemporal_load(reinterpret_cast<const V*>(p)));
 }
+// issue priority of the calling wavefront among the wavefronts of its SIMD (0 = default ... 3)
+template <int P>
+__device__ __forceinline__ void adsb_setprio() { __builtin_amdgcn_s_setprio(P); }
 // written once, read once much later (k_detect's burst lists): non-temporal store
 typedef unsigned long long adsb_u64x2 __attribute__((ext_vector_type(2)));
 template <class T>

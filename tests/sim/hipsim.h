@@ -199,6 +199,7 @@ inline int adsb_opaque(int v) { return v; }
 inline unsigned adsb_after(unsigned v, float) { return v; }
 #define ADSB_LDS
 template <class Q> inline Q adsb_ld_stream(const char* p) { Q q; memcpy(&q, p, sizeof(Q)); return q; }
+template <int P> inline void adsb_setprio() {}
 typedef unsigned long long adsb_u64x2 __attribute__((vector_size(16)));
 template <class T> inline void adsb_st_stream(T* p, T v) { memcpy(p, &v, sizeof(T)); }
 inline int adsb_readlane(int v, int lane) { return hipsim_shfl_idx(v, lane); }

@@ -39,7 +39,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # environment variables the bench knows about; any other ADSB_* variable is refused (a stray tuning knob must never
 # produce an unlabelled number), the known ones are recorded in config.env
 KNOWN_ENV = ("ADSB_BENCH_ONE_GPU", "ADSB_SHARD_EXCHANGE", "ADSB_HIP_LIB", "ADSB_BENCH_SPAWNED")
-DF_MIX = ((11, 0, 4, 17, 20, 5, 21), (2335, 1395, 732, 582, 61, 34, 32))   # reference docs/DF_histogram.txt:4-21
+# reference docs/DF_histogram.txt:4-35: the formats BASELINE config 5 names (DF0/4/5/11/16/17) plus the two other long
+# formats the histogram holds more than a handful of (DF20/21), each at its counted weight (DF16: 2 of 5187)
+DF_MIX = ((11, 0, 4, 17, 20, 5, 21, 16), (2335, 1395, 732, 582, 61, 34, 32, 2))
 
 
 def gen_stream_blocks(n_local, origin, fs, bursts_per_s, seed, device, block=1 << 22, **synth):
@@ -244,7 +246,7 @@ def extra_configs(args, dev, depth):
              workload="synthetic 20 Msps complex64 IQ, 1000 bursts/s, processed as 8 overlapped time shards on this GPU, host stitch"),
         dict(name="config5_mixed_df_low_snr", fs=2e6, bursts=1000.0, seed=4,
              synth=dict(noise_power=2e-3, df_choices=DF_MIX[0], df_weights=DF_MIX[1], snr_db_range=(3.0, 25.0)),
-             workload="synthetic 2 Msps complex64 IQ, 1000 bursts/s mixed DF 0/4/5/11 (56 bit) and 17/20/21 (112 bit) in the "
+             workload="synthetic 2 Msps complex64 IQ, 1000 bursts/s mixed DF 0/4/5/11 (56 bit) and 16/17/20/21 (112 bit) in the "
                       "proportions of docs/DF_histogram.txt, per-burst SNR 3-25 dB over noise power 2e-3"),
     ]
     for sp in specs:
@@ -515,49 +517,57 @@ def host_fed_all_ranks(args, fe, iq, depth, rank, n_gpus, sync_all, ag_obj):
                       "gbytes_per_s": round(n_gpus * reps * chunk * 8 / max(walls) / 1e9, 2) if ok else None}}
 
 
-class ShardedRun:
-    """One rank's side of the N-rank pipeline: its overlapped time shard resident in HBM, `depth` passes in flight; per pass
-    one device pass over the shard, ONE 16-byte exchange of end-of-burst state and the host fix-up of the shard's head
-    (gr_adsb_amd/sharding.py) -- no data-path collective."""
-
-    def __init__(self, fe, iq, plan, stream_len, sps, rank, ag_int, ag_obj, depth):
-        self.fe, self.iq, self.plan, self.stream_len, self.sps, self.rank = fe, iq, plan, stream_len, sps, rank
-        self.ag_int, self.ag_obj, self.depth = ag_int, ag_obj, depth
-        self.pending, self.stash = [], {}      # tickets in flight; results of tickets collected early (fallback path only)
-        self.last_kept, self.last_n, self.stitch_s, self.passes = None, 0, 0.0, 0
-
-    def step(self):
-        from gr_adsb_amd import sharding
-        p = self.plan
-        self.pending.append(self.fe.submit_shard_tensor(self.iq, p["lo"], p["own_lo"], p["own_hi"], self.stream_len,
-                                                        head_cands=sharding.HEAD_CANDS))
-        if len(self.pending) == self.depth:
-            self._collect(self.pending.pop(0))
-
-    def drain(self):
-        while self.pending:
-            self._collect(self.pending.pop(0))
-        return self.last_n
-
-    def _ungated(self):
-        # fallback of sharding.finish_shard: a blocking call is only allowed with no ticket pending, so collect (and keep)
-        # whatever is still in flight first; every rank takes this path together
-        for t in list(self.pending):
-            self.stash[t] = self.fe.wait(t)
-        p = self.plan
-        return self.fe.shard_tensor(self.iq, p["lo"], p["own_lo"], p["own_hi"], self.stream_len)
-
-    def _collect(self, ticket):
-        from gr_adsb_amd import sharding
-        if ticket in self.stash:
-            recs, inplace = self.stash.pop(ticket), False
-        else:
-            recs, inplace = self.fe.wait(ticket, copy=False), True      # view of the pinned result buffer, fixed up in place
-        t_x = time.perf_counter()
-        kept = sharding.finish_shard(recs, self.sps, self.rank, self.ag_int, self._ungated, self.ag_obj, inplace=inplace)
-        self.stitch_s += time.perf_counter() - t_x
-        self.passes += 1
-        self.last_kept, self.last_n = kept, len(kept)
+def one_process_leg(args, devices, context_counts=None, fs=20e6, bursts=1000.0, seed=3):
+    """ONE process, N devices, ONE page-locked host ring (adsb_process_sharded_multi; BASELINE config 4's stream, 20 Msps): the
+    stream is tiled into overlapped time shards inside the library, one feeder thread per context, seams stitched on the
+    host.  PCIe-inclusive (never the bench `value`).  devices: HIP ordinals, one context each; context_counts: also run with
+    that many contexts on devices[0] (how a one-GPU box exercises the driver).  Every run is compared with ONE blocking
+    canonical call over the whole ring."""
+    import torch
+    from gr_adsb_amd import _native
+    from gr_adsb_amd.frontend import MultiDevice
+    per_dev = 1 << args.hostfed_log2n
+    runs = [("one context per device", list(devices))] + [("%d contexts on device %d" % (k, devices[0]), [devices[0]] * k)
+                                                          for k in (context_counts or [])]
+    out = {"entry_point": "adsb_process_sharded_multi (complex64, one page-locked ring, feeder thread per context)",
+           "workload": "synthetic %g Msps complex64 IQ, %g bursts/s, seed %d; 2^%d samples per context" % (fs / 1e6, bursts, seed, args.hostfed_log2n),
+           "runs": []}
+    ring, want, n_have = None, None, 0
+    for what, devs in runs:
+        n = per_dev * len(devs)
+        md = MultiDevice(fs, args.threshold, devices=devs)
+        try:
+            if n != n_have:
+                ring = md.pinned(n, np.complex64)
+                with torch.cuda.device(devs[0]):
+                    blk = 1 << 24
+                    for o in range(0, n, blk):           # generated on the device in blocks, copied down: the ring is host memory
+                        m = min(blk, n - o)
+                        ring.array[o:o + m] = gen_stream_blocks(m, o, fs, bursts, seed, torch.device("cuda", devs[0]))[:m] \
+                            .cpu().numpy().view(np.complex64).reshape(-1)
+                want = md.contexts[0].process_format(_native.FMT_FC32, ring.array)
+                want["flags"] &= ~np.uint16(_native.BURST_HEAD)
+                n_have = n
+            rec = {"what": what, "contexts": len(devs), "devices": [int(d) for d in devs], "samples": n, "legs": []}
+            for spc in (1, 4):
+                got = md.process_host(_native.FMT_FC32, ring.array, spc)
+                same = bool(got.tobytes() == want.tobytes())
+                tt = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    md.process_host(_native.FMT_FC32, ring.array, spc, out=got if len(got) else None)
+                    tt.append(time.perf_counter() - t0)
+                dt = float(np.median(tt))
+                st = md.last_stats
+                rec["legs"].append({"shards_per_context": spc, "value": round(n / dt / 1e6, 1), "unit": "Msamples/s",
+                                    "gbytes_per_s": round(n * 8 / dt / 1e9, 2), "ms": round(dt * 1e3, 3), "bursts": int(len(got)),
+                                    "identical_to_one_blocking_call": same, "fallbacks": int(st["fallbacks"]),
+                                    "feeder_ms": [round(x * 1e3, 3) for x in st["feeder_s"]], "numa_node": st["numa_node"]})
+            out["runs"].append(rec)
+        finally:
+            md.close()
+    del ring
+    return out
 
 
 def sharded_leg(args, dev, rank, n_gpus, fs, bursts, seed, n_own, steps, warmup, min_time, depth, sync_all, reduce_max,
@@ -574,7 +584,7 @@ def sharded_leg(args, dev, rank, n_gpus, fs, bursts, seed, n_own, steps, warmup,
     plan = shard_plan(stream_len, n_gpus, sps, align=n_own)[rank]
     iq = gen_stream_blocks(plan["hi"] - plan["lo"], plan["lo"], fs, bursts, seed, dev, **synth)
     torch.cuda.synchronize()
-    run = ShardedRun(fe, iq, plan, stream_len, sps, rank, ag_int, ag_obj, depth)
+    run = sharding.ShardedRank(fe, iq, plan, stream_len, rank, ag_int, ag_obj, depth)
     fb0 = sharding.STATS["fallbacks"]
     for _ in range(warmup):
         run.step()
@@ -608,7 +618,7 @@ def sharded_leg(args, dev, rank, n_gpus, fs, bursts, seed, n_own, steps, warmup,
         # stream per pipeline slot; the timed contexts above keep their k_detect launches in line so that every event pair
         # brackets one launch) -- a wall time only, three repeats, every rank takes part (the exchange is collective)
         fe2 = FrontEnd(fs, args.threshold, device=dev.index, timing=False)
-        run2 = ShardedRun(fe2, iq, plan, stream_len, sps, rank, ag_int, ag_obj, depth)
+        run2 = sharding.ShardedRank(fe2, iq, plan, stream_len, rank, ag_int, ag_obj, depth)
         for _ in range(warmup):
             run2.step()
         run2.drain()
@@ -696,6 +706,9 @@ def main():
                     help="with --gpus N > 1: skip the PCIe-inclusive leg (every rank feeding its GPU from page-locked host memory)")
     ap.add_argument("--no-config4", action="store_true",
                     help="with --gpus N > 1: skip BASELINE config 4's legs (one 20 Msps stream tiled as N overlapped shards, weak and strong)")
+    ap.add_argument("--no-one-process", action="store_true",
+                    help="with --gpus N > 1: skip the leg in which rank 0 alone drives all N devices from one host ring "
+                         "(adsb_process_sharded_multi)")
     ap.add_argument("--mixed-df", action="store_true",
                     help="BASELINE config 5's signal as the main workload: DF mix of docs/DF_histogram.txt, SNR 3-25 dB over noise 2e-3")
     ap.add_argument("--force-dist", action="store_true",
@@ -913,12 +926,13 @@ def main():
                        "ms_per_step_max": round(max(times) / args.steps * 1e3, 4),
                        "note": "each repeat = exactly `steps` steps between barrier+synchronize, max over ranks; value uses the median repeat"},
             "config": {
-                "workload": "synthetic %g Msps %s IQ, %g %s bursts/s, %s, threshold %g; "
-                            "2^%d samples per GPU per step resident in HBM; one canonical framer+demod pass"
-                            % (fs / 1e6, {"fc32": "complex64", "mag2": "float32 |IQ|^2 of complex64", "sc16": "int16", "sc8": "int8", "cu8": "uint8 offset-binary"}[args.format], args.bursts,
-                               "mixed-DF (docs/DF_histogram.txt proportions, SNR 3-25 dB)" if args.mixed_df else "DF17-length",
+                # (kept under 130 characters: a reader that cuts long strings still sees all of it)
+                "workload": "synthetic %g Msps %s IQ, %g %s bursts/s, %s, thr %g; 2^%d samples/GPU/step in HBM"
+                            % (fs / 1e6, {"fc32": "complex64", "mag2": "f32 |IQ|^2", "sc16": "int16", "sc8": "int8", "cu8": "uint8"}[args.format], args.bursts,
+                               "mixed-DF 3-25 dB" if args.mixed_df else "DF17",
                                "AWGN 2e-3" if args.mixed_df else "AWGN 1e-3", args.threshold, args.log2n),
-                "fs": fs, "samples_per_gpu_per_step": n_own, "bursts_per_step_rank0": int(n_bursts),
+                "samples_per_gpu_per_step": n_own, "fs": fs, "bursts_per_step_rank0": int(n_bursts),
+                "step": "one canonical framer+demod pass (|IQ|^2, preamble detect + tag, gate, PPM slice, records to pinned host memory)",
                 "sharding": "none" if n_gpus == 1 else "%d overlapped time shards, host stitch" % n_gpus,
                 "rank_sync": rank_sync,
                 "launched_by": "bench.py itself (torch.distributed.run)" if os.environ.get("ADSB_BENCH_SPAWNED") == "1" else (
@@ -948,6 +962,12 @@ def main():
                 result["host_fed"] = hf_multi
             if cfg4 is not None:
                 result["config4_20msps"] = cfg4
+            if not args.no_one_process and not one_gpu:
+                # ONE process driving every GPU of the node from one host ring (the other ranks are idle at the closing barrier)
+                try:
+                    result["one_process"] = one_process_leg(args, list(range(min(n_gpus, torch.cuda.device_count()))))
+                except Exception as e:                           # noqa: BLE001  (the headline line must not be lost)
+                    result["one_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_cpu and n_gpus == 1 and not intfmt:
             n_cpu = min(n_own, 1 << args.cpu_log2n)
             host = iq[:n_cpu].cpu().numpy().view(np.complex64).reshape(-1)
@@ -983,6 +1003,7 @@ def main():
                 "structure of framer.py:83-174 / demod.py:67-110 (|IQ|^2 given); pinned to the goldens and the real reference")
         if n_gpus == 1 and not intfmt and not args.no_hostfed:
             result["host_fed"] = host_fed_record(args, fe, iq, DEPTH)
+            result["host_fed"]["one_process"] = one_process_leg(args, [local_rank], context_counts=[3, 8])
         if n_gpus == 1 and not intfmt and not args.no_extra:
             del iq
             torch.cuda.empty_cache()
@@ -1000,6 +1021,7 @@ def main():
         for rec in result.get("extra_configs", []) + result.get("formats", []):
             key = rec["name"].split("_")[0].replace("config", "cfg") if rec["name"].startswith("config") else rec["format"]
             cfgd[key + "_frac"] = rec["roofline"]["frac"]
+            cfgd[key + "_frac_isolated"] = (rec["roofline"].get("isolated") or {}).get("frac")
             cfgd[key + "_ms"] = rec["ms_per_step"]
             if "product_default" in rec:
                 cfgd[key + "_ms_untimed_ctx"] = rec["product_default"]["ms_per_step"]
@@ -1012,6 +1034,11 @@ def main():
             cfgd["hostfed_%s_pinned_msps" % name] = rec["pinned"]["value"]
             cfgd["hostfed_%s_pageable_msps" % name] = rec["pageable"]["value"]
             cfgd["hostfed_%s_pinned_vs_plain_h2d" % name] = rec["pinned_vs_plain_h2d"]
+        op = (result.get("host_fed", {}).get("one_process") or result.get("one_process") or {}).get("runs", [])
+        for r_ in op:
+            best = max(r_["legs"], key=lambda l_: l_["value"])
+            cfgd["one_process_%dctx_msps" % r_["contexts"]] = best["value"]
+            cfgd["one_process_%dctx_identical" % r_["contexts"]] = all(l_["identical_to_one_blocking_call"] for l_ in r_["legs"])
         if n_gpus > 1 and result.get("multi_gpu"):
             cfgd["seams_identical"] = bool(result["multi_gpu"]["seam_check"]["all_identical"])
             cfgd["stitch_fallbacks"] = int(result["multi_gpu"]["stitch_fallbacks_total"])
@@ -1026,6 +1053,7 @@ def main():
                         cfgd["cfg4_%s_ms_untimed_ctx" % leg_name] = cfg4[leg_name]["product_default"]["ms_per_step"]
                     cfgd["cfg4_%s_seams_identical" % leg_name] = bool(cfg4[leg_name]["seam_check"]["all_identical"])
                     cfgd["cfg4_%s_per_rank_frac" % leg_name] = [r_["roofline_frac"] for r_ in cfg4[leg_name]["per_rank"]]
+        result["config"] = order_config(cfgd, n_gpus)
         print(json.dumps(result), flush=True)
     if n_gpus > 1:
         sync_all()
@@ -1033,6 +1061,28 @@ def main():
     if dist_on:
         dist.destroy_process_group()
     return result
+
+
+# The per-leg verdicts a reader must not lose come FIRST in `config` (a record that keeps only the first two dozen keys
+# of the line -- the driver's BENCH_rNN.json does -- still holds every BASELINE config and every input format):
+# workload, size, then roofline fraction live / alone and the bit-match of configs 3, 4, 5 and of the five formats.
+CONFIG_FIRST = (["workload", "samples_per_gpu_per_step"]
+                + ["cfg%d_%s" % (c, k) for c in (3, 4, 5) for k in ("frac", "frac_isolated", "identical")]
+                + ["cfg4_8shards_msps"]
+                + ["%s_%s" % (f, k) for f in ("mag2", "sc16", "sc8", "sc8g", "cu8") for k in ("frac", "identical")]
+                + ["hostfed_fc32_pinned_vs_plain_h2d"])
+CONFIG_FIRST_MULTI = ["workload", "samples_per_gpu_per_step", "seams_identical", "stitch_fallbacks", "per_rank_roofline_frac",
+                      "hostfed_total_msps", "cfg4_weak_msps", "cfg4_weak_ms", "cfg4_weak_seams_identical", "cfg4_weak_per_rank_frac",
+                      "cfg4_strong_msps", "cfg4_strong_ms", "cfg4_strong_seams_identical", "cfg4_strong_per_rank_frac",
+                      "cfg4_weak_ms_untimed_ctx", "cfg4_strong_ms_untimed_ctx", "sharding", "rank_sync", "launched_by"]
+# (+ one_process_<N>ctx_msps / _identical right behind them, see order_config)
+
+
+def order_config(cfgd, n_gpus):
+    first = CONFIG_FIRST if n_gpus == 1 else CONFIG_FIRST_MULTI + sorted(k for k in cfgd if k.startswith("one_process_"))
+    out = {k: cfgd[k] for k in first if k in cfgd}
+    out.update((k, v) for k, v in cfgd.items() if k not in out)
+    return out
 
 
 def untimed_context_ms(args, device, fmt, iq, n, depth, sync_all, repeats=3, fs=None, scale=None, steps=None):

@@ -22,7 +22,7 @@ FLAG_SINGLE_STREAM = 8    # profiling aid: the sparse tail of a pass on the comp
 FLAG_FRAMER_SLICES = 32   # adsb_framer_work also returns the 112 bits of tags whose burst ends inside the call's input
 FLAG_NO_NUMA_BINDING = 64 # host side not placed on the GPU's NUMA node (default: page-locked buffers and copy threads are)
 FLAG_LOW_LATENCY = 16     # the tail of a pass runs beside the next pass's k_detect: results a pass earlier, 1-2 % less throughput
-ABI_VERSION = 4
+ABI_VERSION = 5
 # input sample formats (include/adsb_hip.h ADSB_FMT_*): numpy dtype of the flat host array, items per sample
 FMT_FC32, FMT_MAG2, FMT_SC16, FMT_SC8, FMT_CU8 = 0, 1, 2, 3, 4
 FMT_LAYOUT = {FMT_FC32: (np.complex64, 1), FMT_MAG2: (np.float32, 1), FMT_SC16: (np.int16, 2), FMT_SC8: (np.int8, 2),
@@ -45,6 +45,7 @@ EXPORTS = [
     "adsb_set_format_scale", "adsb_process_format", "adsb_process_format_device", "adsb_submit_format_device",
     "adsb_submit_format_host", "adsb_last_confidence",
     "adsb_framer_work", "adsb_demod_work", "adsb_shard_bounds", "adsb_process_sharded_device", "adsb_shard_device", "adsb_shard_host", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_mode_s_syndrome", "adsb_plan_chunks", "adsb_get_stats",
+    "adsb_process_sharded_multi", "adsb_device_alloc", "adsb_device_free", "adsb_device_upload", "adsb_clear_pending_events",
     "adsb_reset_stats", "adsb_detect_history", "adsb_numa_info", "adsb_host_alloc_near", "adsb_last_error", "adsb_host_alloc", "adsb_host_free", "adsb_host_register", "adsb_host_unregister",
 ]
 
@@ -55,6 +56,15 @@ class Stats(ctypes.Structure):
                 ("longrun_calls", ctypes.c_uint64), ("detect_grid", ctypes.c_uint64), ("blocks_per_cu", ctypes.c_uint64),
                 ("detect_gap_ms", ctypes.c_double), ("detect_gaps", ctypes.c_uint64), ("longrun_pulses", ctypes.c_uint64),
                 ("poll_fallbacks", ctypes.c_uint64), ("shard_fallbacks", ctypes.c_uint64)]
+
+
+MULTI_MAX_CTX = 64
+
+
+class MultiStats(ctypes.Structure):
+    _fields_ = [("contexts", ctypes.c_int32), ("shards", ctypes.c_int32), ("fallbacks", ctypes.c_int32), ("pad_", ctypes.c_int32),
+                ("wall_s", ctypes.c_double), ("feeder_s", ctypes.c_double * MULTI_MAX_CTX),
+                ("device", ctypes.c_int32 * MULTI_MAX_CTX), ("numa_node", ctypes.c_int32 * MULTI_MAX_CTX)]
 
 
 class AdsbError(RuntimeError):
@@ -122,6 +132,11 @@ def load():
     lib.adsb_shard_bounds.argtypes = [i64, i32, i32, c.c_int, i64, c.POINTER(i64), c.POINTER(i64), c.POINTER(i64), c.POINTER(i64)]
     lib.adsb_shard_bounds.restype = c.c_int32
     lib.adsb_process_sharded_device.argtypes = [vp, c.c_int, vp, i64, i64, i32, vp, i32, c.POINTER(i32)]
+    lib.adsb_process_sharded_multi.argtypes = [c.POINTER(vp), i32, c.c_int, vp, i64, i64, i32, vp, i32, c.POINTER(i32), c.POINTER(MultiStats)]
+    lib.adsb_device_alloc.argtypes = [vp, c.POINTER(vp), c.c_size_t]
+    lib.adsb_device_free.argtypes = [vp, vp]
+    lib.adsb_device_upload.argtypes = [vp, vp, vp, c.c_size_t]
+    lib.adsb_clear_pending_events.argtypes = [vp]
     lib.adsb_stitch.argtypes = [vp, i32, c.c_int, c.POINTER(i32)]
     lib.adsb_snr_db.argtypes = [f32, f32]
     lib.adsb_snr_db.restype = f32
@@ -329,6 +344,22 @@ class Context:
         """Everything submitted next runs after this hipEvent_t (raw handle) has completed: device-side ordering."""
         self._chk(self.lib.adsb_wait_for_event(self._h, ctypes.c_void_p(int(hip_event))))
 
+    def clear_pending_events(self):
+        self._chk(self.lib.adsb_clear_pending_events(self._h))
+
+    def device_alloc(self, nbytes):
+        """Device memory on this context's device (adsb_device_alloc) -> raw pointer; device_free it."""
+        d = ctypes.c_void_p()
+        self._chk(self.lib.adsb_device_alloc(self._h, ctypes.byref(d), int(nbytes)))
+        return int(d.value)
+
+    def device_free(self, dev_ptr):
+        self._chk(self.lib.adsb_device_free(self._h, ctypes.c_void_p(int(dev_ptr))))
+
+    def device_upload(self, dev_ptr, data):
+        data = np.ascontiguousarray(data)
+        self._chk(self.lib.adsb_device_upload(self._h, ctypes.c_void_p(int(dev_ptr)), ctypes.c_void_p(data.ctypes.data), data.nbytes))
+
     def framer_state(self):
         """(prev_in0, prev_eob_idx): the reference framer's cross-call attributes (framer.py:54,57)."""
         p, e = ctypes.c_float(0), ctypes.c_int64(0)
@@ -475,6 +506,37 @@ class RegisteredArray:
             self.close()
         except Exception:
             pass
+
+
+def process_sharded_multi(contexts, fmt, data, shards_per_ctx=1, abs_offset=0, out=None, want_stats=False):
+    """ONE host buffer, N contexts (normally one per device), one stitched burst list: adsb_process_sharded_multi.  data =
+    host array in the format's layout (FMT_LAYOUT; a PinnedArray / RegisteredArray view is DMA'd where it lies).  Returns the
+    records -- bit-identical to Context.process_format over the whole buffer -- and, with want_stats, the per-context
+    timings of the call as a dict."""
+    lib = load()
+    dt, per = FMT_LAYOUT[int(fmt)]
+    data = np.ascontiguousarray(data, dtype=dt)
+    n = len(data) // per
+    arr = (ctypes.c_void_p * len(contexts))(*[cx._h for cx in contexts])
+    if out is None:
+        out = np.empty(max(4096, n // 4096), dtype=BURST_DTYPE)
+    st = MultiStats()
+    while True:
+        n_out = ctypes.c_int32(0)
+        rc = lib.adsb_process_sharded_multi(arr, len(contexts), int(fmt), ctypes.c_void_p(data.ctypes.data), n, int(abs_offset),
+                                            int(shards_per_ctx), out.ctypes.data_as(ctypes.c_void_p), len(out),
+                                            ctypes.byref(n_out), ctypes.byref(st))
+        if rc == -errno.ENOSPC and n_out.value > len(out):
+            out = np.empty(n_out.value + n_out.value // 8 + 16, dtype=BURST_DTYPE)
+            continue
+        if rc != 0:
+            raise AdsbError(rc, lib.adsb_last_error(contexts[0]._h).decode("utf-8", "replace") if contexts else "")
+        recs = out[:n_out.value]
+        if not want_stats:
+            return recs
+        k = st.contexts
+        return recs, {"contexts": k, "shards": st.shards, "fallbacks": st.fallbacks, "wall_s": st.wall_s,
+                      "feeder_s": list(st.feeder_s[:k]), "device": list(st.device[:k]), "numa_node": list(st.numa_node[:k])}
 
 
 def stitch(cands, sps):

@@ -311,6 +311,7 @@ struct adsb_ctx {
   hipEvent_t ext_ev[kMaxExt] = {nullptr, nullptr, nullptr, nullptr};
   int n_ext = 0;
   hipStream_t h2d_stream = nullptr;   // host-fed submissions: sample uploads, back to back on their own stream
+  hipStream_t d2h_stream = nullptr;   // record copies of passes whose own streams are shared with later passes (created on first use)
   bool split_tail = false;
   bool own_stream = false;
   int n_cu = 256;
@@ -651,8 +652,8 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl, bool submitted) {
       //    end for the next launch to fill, and two instruction-bound launches side by side slow each other down (int8,
       //    2^30 samples: 0.568 ms in line, 0.607-0.617 overlapped; at 2^28 samples the same either way, below that the
       //    overlap wins by up to 20 %: profiles/r05_ab_8bit_workgroup_shape_and_schedule.txt).
-      // No stream is added for that: the three slot streams take the three roles -- slot 0's every k_detect, slot 1's every
-      // tail, slot 2's the record copies (finish) -- because the runtime multiplexes all streams of a process onto FOUR
+      // No stream is added for the kernels: slot 0's stream takes every k_detect, slot 1's every tail (the record copies have
+      // the context's copy stream, finish) -- because the runtime multiplexes all streams of a process onto FOUR
       // hardware queues (GPU_MAX_HW_QUEUES), and a k_detect stream that shares its queue with a stream whose tail waits for
       // that k_detect stalls behind it: with a fourth stream for k_detect the timed 2^28-sample legs ran 10 % slower than
       // in round 4 (profiles/r05_pass_cost_timed_with_a_fourth_stream.txt).
@@ -834,9 +835,12 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
     if (nres > 0 && (!in_host || (c->flags & ADSB_FLAG_CONFIDENCE))) {
       // on the pass's own stream (idle: its last kernel has completed); never on a caller-owned one
       // (a submitted pass that shares its stream with the passes behind it -- kernels in line, or ADSB_FLAG_SINGLE_STREAM --
-      // copies on slot 2's stream: on its own one the copy would wait for everything queued since)
+      // copies on the context's record-copy stream: on its own one the copy would wait for everything queued since)
+      // (a copy stream of its own, not a slot's: a slot's stream may hold a LATER pass -- slot 2's own overlapped pass, an
+      // in-line pass's tail -- and the copy of an older pass would wait for it)
       const bool shared = s.ds != s.cs || (s.submitted && !c->split_tail);
-      const hipStream_t xs = !c->own_stream ? c->copy_stream : (shared ? c->slot[2].stream : s.cs);
+      if (c->own_stream && shared && !c->d2h_stream) FINCHK(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+      const hipStream_t xs = !c->own_stream ? c->copy_stream : (shared ? c->d2h_stream : s.cs);
       if (!in_host)
         FINCHK(hipMemcpyAsync(s.h_out, s.d_out.p, (size_t)nres * sizeof(Rec), hipMemcpyDeviceToHost, xs));
       if (c->flags & ADSB_FLAG_CONFIDENCE) {
@@ -1083,6 +1087,7 @@ void adsb_destroy(adsb_ctx* c) {
   if (!c->own_stream && c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   if (c->h2d_stream) (void)hipStreamSynchronize(c->h2d_stream);
+  if (c->d2h_stream) (void)hipStreamSynchronize(c->d2h_stream);
   if (c->tail_stream) (void)hipStreamSynchronize(c->tail_stream);
   for (Slot& sl : c->slot) if (sl.stream) (void)hipStreamSynchronize(sl.stream);
   DevBuf* bufs[] = {&c->d_in};
@@ -1108,6 +1113,7 @@ void adsb_destroy(adsb_ctx* c) {
   for (hipEvent_t e : c->ring_done) if (e) (void)hipEventDestroy(e);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
+  if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
   if (c->tail_stream) (void)hipStreamDestroy(c->tail_stream);
   delete c;
 }
@@ -1177,9 +1183,16 @@ int adsb_wait_for_event(adsb_ctx* c, void* hip_event) {
   return 0;
 }
 
+int adsb_clear_pending_events(adsb_ctx* c) {
+  if (!c) return -EINVAL;
+  c->n_ext = 0;
+  return 0;
+}
+
 int adsb_reset(adsb_ctx* c) {
   if (!c) return -EINVAL;
   c->st = FramerState();
+  c->n_ext = 0;           // a fresh stream starts without remembered producers
   return 0;
 }
 
@@ -1547,8 +1560,18 @@ int adsb_process_sharded_device(adsb_ctx* c, int fmt, const void* d_data, int64_
   if (!c || fmt < 0 || fmt >= ADSB_FMT_COUNT || n < 0 || shards < 1 || cap < 0 || (cap > 0 && !out) || !n_out) return -EINVAL;
   if (((uintptr_t)d_data & 15u) != 0) return fail(c, -EINVAL, "device pointer must be 16-byte aligned");
   for (const Slot& sl : c->slot) if (sl.busy) return fail(c, -EBUSY, "a submitted call is still pending (adsb_wait first)");
+  // the rows of adsb_last_confidence belong to the records of ONE pass in the order that pass delivered them; this driver
+  // re-gates and concatenates the records of many passes on the host
+  if (c->flags & ADSB_FLAG_CONFIDENCE) return fail(c, -EINVAL, "adsb_process_sharded_device: not for ADSB_FLAG_CONFIDENCE contexts");
   *n_out = 0;
   if (n == 0) return 0;
+  // adsb_wait_for_event: EVERY shard pass reads the caller's buffer and the passes run on different streams, so every
+  // one of them (the re-runs of the fallback included) waits for the pending events -- enqueue() applies and clears what
+  // is pending, the driver puts the same events back in front of each of its passes
+  hipEvent_t ext_snap[adsb_ctx::kMaxExt];
+  const int n_ext_snap = c->n_ext;
+  for (int i = 0; i < n_ext_snap; ++i) ext_snap[i] = c->ext_ev[i];
+  auto rearm = [&]() { for (int i = 0; i < n_ext_snap; ++i) c->ext_ev[i] = ext_snap[i]; c->n_ext = n_ext_snap; };
   const int bps = mode_bytes(fmt);
   struct Pend { int ticket; long long own_lo, own_hi, lo, hi; };
   Pend pend[ADSB_MAX_IN_FLIGHT];
@@ -1579,6 +1602,7 @@ int adsb_process_sharded_device(adsb_ctx* c, int fmt, const void* d_data, int64_
         Plan pl;
         if ((r = shard_plan_checked(c, fmt, (const char*)d_data + (size_t)p.lo * bps, p.hi - p.lo, p.lo, p.own_lo, p.own_hi, n,
                                     attempt == 0 ? 4096 : 0, &pl))) return r;
+        rearm();
         if ((r = enqueue(c, s, pl, true))) { s.busy = false; return r; }
         if ((r = finish(c, s, &sum, &nres))) return r;
         if ((r = shard_post(c, s, sum, &nres))) return r;
@@ -1610,6 +1634,7 @@ int adsb_process_sharded_device(adsb_ctx* c, int fmt, const void* d_data, int64_
     Plan pl;
     if ((rc = shard_plan_checked(c, fmt, (const char*)d_data + (size_t)lo * bps, hi - lo, lo, own_lo, own_hi, n, kHead, &pl))) break;
     Slot& s = c->slot[c->next_slot];
+    rearm();
     if ((rc = enqueue(c, s, pl, true))) { s.busy = false; break; }
     s.is_shard = true;
     pend[(head + n_pend) % ADSB_MAX_IN_FLIGHT] = Pend{c->next_slot, own_lo, own_hi, lo, hi};
@@ -1620,9 +1645,232 @@ int adsb_process_sharded_device(adsb_ctx* c, int fmt, const void* d_data, int64_
     const int r = collect();          // (after an error too: no pass stays in flight behind this call)
     if (r && !rc) rc = r;
   }
+  c->n_ext = 0;                       // consumed by this call, whether a pass was queued or not
   if (rc) return rc;
   *n_out = (int32_t)(total > 0x7FFFFFFF ? 0x7FFFFFFF : total);
   if (total > cap) return fail(c, -ENOSPC, "output array too small");
+  return 0;
+}
+
+// ---- one process, N devices, one host ring (BASELINE config 4) --------------------------------------------
+// The stream lies in HOST memory; context k (one per device, or several on one) takes `shards_per_ctx` consecutive
+// overlapped time shards of it.  One feeder thread per context, inside the cpus local to its GPU: upload of shard i+1 on
+// the context's upload stream beside the shard pass of i and the record download of i-1, ADSB_MAX_IN_FLIGHT deep -- the
+// host-fed pipeline of adsb_submit_format_host with a shard plan.  The calling thread takes the finished shards in STREAM
+// order as they arrive and re-gates each head with the end-of-burst state carried over the seam (adsb_shard_fixup); a head
+// that ends inside an unbroken chain has its shard run again on its own context (largest head, then ungated + the plain
+// greedy gate), after that context's feeder has finished.  No interpreter, no torch.distributed, no mailbox: the only
+// thing that crosses a seam is one int64.
+namespace {
+
+struct MultiShard {
+  long long own_lo = 0, own_hi = 0, lo = 0, hi = 0;
+  std::vector<adsb_burst> recs;      // the shard's records as its pass delivered them (head + what a fresh-state gate kept)
+  int rc = 0;
+  bool done = false;
+};
+
+// queue one shard of a host-resident stream on the context's next slot: upload -> shard pass
+int submit_shard_host(adsb_ctx* c, int fmt, const char* host, const MultiShard& sh, long long stream_len, int head, int32_t* ticket) {
+  Slot& s = c->slot[c->next_slot];
+  if (s.busy) return fail(c, -EBUSY, "every pipeline slot is in flight");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int bps = mode_bytes(fmt);
+  int rc = upload_async(c, s, host + (size_t)sh.lo * bps, (size_t)(sh.hi - sh.lo) * bps);
+  if (rc) return rc;
+  Plan pl;
+  if ((rc = shard_plan_checked(c, fmt, s.d_in.p, sh.hi - sh.lo, sh.lo, sh.own_lo, sh.own_hi, stream_len, head, &pl))) return rc;
+  if ((rc = enqueue(c, s, pl, true))) { s.busy = false; return rc; }
+  s.is_shard = true;
+  *ticket = c->next_slot;
+  c->next_slot = (c->next_slot + 1) % ADSB_MAX_IN_FLIGHT;
+  return 0;
+}
+
+int collect_shard(adsb_ctx* c, int32_t ticket, std::vector<adsb_burst>* out) {
+  Slot& s = c->slot[ticket];
+  Summary sum;
+  int32_t nres = 0;
+  int r = finish(c, s, &sum, &nres);
+  if (r) return r;
+  c->last_slot = ticket;
+  if ((r = shard_post(c, s, sum, &nres))) return r;
+  const adsb_burst* recs = (const adsb_burst*)s.h_out;
+  out->assign(recs, recs + nres);
+  return 0;
+}
+
+}  // namespace
+
+int adsb_process_sharded_multi(adsb_ctx* const* ctxs, int32_t n_ctx, int fmt, const void* host, int64_t n, int64_t abs_offset,
+                               int32_t shards_per_ctx, adsb_burst* out, int32_t cap, int32_t* n_out, adsb_multi_stats* stats) {
+  if (!ctxs || n_ctx < 1 || n_ctx > ADSB_MULTI_MAX_CTX || fmt < 0 || fmt >= ADSB_FMT_COUNT || n < 0 || shards_per_ctx < 1 ||
+      cap < 0 || (cap > 0 && !out) || !n_out || (n > 0 && !host)) return -EINVAL;
+  adsb_ctx* c0 = ctxs[0];
+  if (!c0) return -EINVAL;
+  for (int k = 0; k < n_ctx; ++k) {
+    adsb_ctx* c = ctxs[k];
+    if (!c) return -EINVAL;
+    for (int j = 0; j < k; ++j) if (ctxs[j] == c) return fail(c0, -EINVAL, "adsb_process_sharded_multi: a context listed twice");
+    // one stream, one set of rules: every context must have been created with the same rate, threshold, gate and scale
+    if (c->sps != c0->sps || !(c->thr == c0->thr) || ((c->flags ^ c0->flags) & ADSB_FLAG_LONG_AWARE_GATE) ||
+        !(c->scale[fmt] == c0->scale[fmt]))
+      return fail(c0, -EINVAL, "adsb_process_sharded_multi: contexts differ in rate, threshold, gate or format scale");
+    if (c->flags & ADSB_FLAG_CONFIDENCE) return fail(c0, -EINVAL, "adsb_process_sharded_multi: not for ADSB_FLAG_CONFIDENCE contexts");
+    if (!c->own_stream) return fail(c0, -EINVAL, "adsb_process_sharded_multi: not for contexts on a caller-owned stream");
+    for (const Slot& sl : c->slot) if (sl.busy) return fail(c0, -EBUSY, "a submitted call is still pending on one of the contexts");
+  }
+  *n_out = 0;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n == 0) return 0;
+  const int sps = c0->sps, kHead = 64;
+  const int G = n_ctx * shards_per_ctx;
+  const auto t_start = std::chrono::steady_clock::now();
+
+  std::vector<MultiShard> sh((size_t)G);
+  for (int g = 0; g < G; ++g) {
+    int64_t olo, ohi, lo, hi;
+    const int rc = adsb_shard_bounds(n, G, g, sps, 4096, &olo, &ohi, &lo, &hi);
+    if (rc) return rc;
+    sh[(size_t)g].own_lo = olo; sh[(size_t)g].own_hi = ohi; sh[(size_t)g].lo = lo; sh[(size_t)g].hi = hi;
+  }
+  std::mutex m;
+  std::condition_variable cv;
+  std::vector<double> feed_s((size_t)n_ctx, 0.0);
+
+  // context k's feeder: its shards, ADSB_MAX_IN_FLIGHT deep.  An error ends this feeder only (its remaining shards are
+  // marked done with the error) -- and nothing of its context stays in flight behind it.
+  auto feeder = [&](int k) {
+    adsb_ctx* c = ctxs[k];
+    if (c->have_local_cpus && !(c->flags & ADSB_FLAG_NO_NUMA_BINDING)) {
+      cpu_set_t mine, both;
+      CPU_ZERO(&mine);
+      if (sched_getaffinity(0, sizeof(mine), &mine) == 0) {
+        CPU_AND(&both, &mine, &c->local_cpus);
+        if (CPU_COUNT(&both) > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof(both), &both);
+      }
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const int g0 = k * shards_per_ctx, g1 = g0 + shards_per_ctx;
+    struct Fly { int g; int32_t ticket; };
+    Fly fly[ADSB_MAX_IN_FLIGHT];
+    int n_fly = 0, head = 0, rc = 0;
+    auto mark = [&](int g, int r) {
+      { std::lock_guard<std::mutex> lk(m); sh[(size_t)g].rc = r; sh[(size_t)g].done = true; }
+      cv.notify_all();
+    };
+    auto collect_oldest = [&]() {
+      const Fly f = fly[head];
+      head = (head + 1) % ADSB_MAX_IN_FLIGHT; --n_fly;
+      std::vector<adsb_burst> recs;
+      const int r = collect_shard(c, f.ticket, &recs);
+      if (r && !rc) rc = r;
+      { std::lock_guard<std::mutex> lk(m); sh[(size_t)f.g].recs.swap(recs); }
+      mark(f.g, r ? r : rc);
+    };
+    int g = g0;
+    for (; g < g1 && !rc; ++g) {
+      if (sh[(size_t)g].own_hi <= sh[(size_t)g].own_lo) { mark(g, 0); continue; }     // (a stream shorter than the tiling: nothing owned)
+      if (n_fly == ADSB_MAX_IN_FLIGHT) collect_oldest();
+      if (rc) break;
+      int32_t ticket = -1;
+      const int r = submit_shard_host(c, fmt, (const char*)host, sh[(size_t)g], n, kHead, &ticket);
+      if (r) { rc = r; break; }
+      fly[(head + n_fly) % ADSB_MAX_IN_FLIGHT] = Fly{g, ticket};
+      ++n_fly;
+    }
+    while (n_fly > 0) collect_oldest();
+    for (; g < g1; ++g) mark(g, rc ? rc : -EIO);                                     // what an error left unsubmitted
+    feed_s[(size_t)k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  };
+
+  std::vector<std::thread> th;
+  std::vector<char> joined((size_t)n_ctx, 0);
+  th.reserve((size_t)n_ctx);
+  for (int k = 0; k < n_ctx; ++k) th.emplace_back(feeder, k);
+  auto join_one = [&](int k) { if (!joined[(size_t)k]) { th[(size_t)k].join(); joined[(size_t)k] = 1; } };
+
+  // the calling thread: finished shards in stream order, head fix-up with the carried state, records to `out`
+  long long eob = -(1ll << 60);
+  int64_t total = 0;
+  int rc = 0, fallbacks = 0;
+  for (int g = 0; g < G; ++g) {
+    MultiShard& S = sh[(size_t)g];
+    {
+      std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk, [&] { return S.done; });
+    }
+    if (S.rc) { if (!rc) rc = S.rc; continue; }
+    if (rc || S.own_hi <= S.own_lo) continue;
+    adsb_ctx* c = ctxs[g / shards_per_ctx];
+    int32_t kept = 0;
+    int r = adsb_shard_fixup(S.recs.data(), (int32_t)S.recs.size(), sps, eob, &kept);
+    if (r == -EAGAIN) {
+      // the head region ended inside a chain: this shard again on its own context, once its feeder is through with it
+      join_one(g / shards_per_ctx);
+      for (int attempt = 0; attempt < 2 && r == -EAGAIN; ++attempt) {
+        int32_t ticket = -1;
+        if ((r = submit_shard_host(c, fmt, (const char*)host, S, n, attempt == 0 ? 4096 : 0, &ticket))) break;
+        if ((r = collect_shard(c, ticket, &S.recs))) break;
+        if (attempt == 0) r = adsb_shard_fixup(S.recs.data(), (int32_t)S.recs.size(), sps, eob, &kept);
+        else { long long e = eob; kept = gate_from(S.recs.data(), (int32_t)S.recs.size(), sps, &e); r = 0; }
+      }
+      if (!r) { ++fallbacks; c->stats.shard_fallbacks++; }
+    }
+    if (r) { rc = r < 0 ? r : -EIO; if (r == -EAGAIN) rc = -EIO; continue; }
+    if (kept > 0) {
+      const adsb_burst& last = S.recs[(size_t)kept - 1];
+      eob = last.offset + ((last.flags & ADSB_BURST_LONG_HINT) ? 119ll : 63ll) * sps;
+      if (total + kept <= cap) {
+        memcpy(out + total, S.recs.data(), (size_t)kept * sizeof(adsb_burst));
+        if (abs_offset) for (int32_t i = 0; i < kept; ++i) out[total + i].offset += abs_offset;
+      }
+    }
+    total += kept;
+    std::vector<adsb_burst>().swap(S.recs);
+  }
+  for (int k = 0; k < n_ctx; ++k) join_one(k);
+  if (stats) {
+    stats->contexts = n_ctx; stats->shards = G; stats->fallbacks = fallbacks;
+    stats->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    for (int k = 0; k < n_ctx; ++k) {
+      stats->feeder_s[k] = feed_s[(size_t)k];
+      stats->device[k] = ctxs[k]->device;
+      stats->numa_node[k] = ctxs[k]->numa_node;
+    }
+  }
+  if (rc) {
+    for (int k = 0; k < n_ctx; ++k)
+      if (ctxs[k] != c0 && ctxs[k]->err[0] && !c0->err[0]) snprintf(c0->err, sizeof(c0->err), "context %d: %s", k, ctxs[k]->err);
+    return rc;
+  }
+  *n_out = (int32_t)(total > 0x7FFFFFFF ? 0x7FFFFFFF : total);
+  if (total > cap) return fail(c0, -ENOSPC, "output array too small");
+  return 0;
+}
+
+// ---- plain device memory for callers that do not link HIP (C / ctypes clients of the *_device entry points) ---------------
+int adsb_device_alloc(adsb_ctx* c, void** d, size_t bytes) {
+  if (!c || !d || bytes == 0) return -EINVAL;
+  *d = nullptr;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (hipMalloc(d, bytes) != hipSuccess) { (void)hipGetLastError(); *d = nullptr; return fail(c, -ENOMEM, "hipMalloc"); }
+  return 0;
+}
+
+int adsb_device_free(adsb_ctx* c, void* d) {
+  if (!c) return -EINVAL;
+  if (!d) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipFree(d));
+  return 0;
+}
+
+int adsb_device_upload(adsb_ctx* c, void* d, const void* host, size_t bytes) {
+  if (!c || (bytes > 0 && (!d || !host))) return -EINVAL;
+  if (bytes == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));      // blocking: the buffer is ready when this returns
   return 0;
 }
 

@@ -147,3 +147,40 @@ class FrontEnd:
     @staticmethod
     def bits(bursts):
         return _native.unpack_bits(bursts["bits"])[:, :112]
+
+
+class MultiDevice:
+    """ONE process, N devices, ONE host ring (BASELINE config 4 / SURVEY.md §8e as the reference's own process model:
+    examples/adsb_rx.py:242-268 is one process with one IQ source).  Holds one context per device; process_host() hands a
+    host buffer to adsb_process_sharded_multi: the stream is tiled into len(devices) * shards_per_device overlapped time
+    shards, each device's feeder thread (inside the library, on the cpus local to its GPU) uploads and runs its shards
+    ADSB_MAX_IN_FLIGHT deep, the seams are stitched on the host -- the result equals FrontEnd.process_format over the whole
+    buffer bit for bit.  devices: HIP ordinals, e.g. range(torch.cuda.device_count()); an ordinal may repeat (several
+    contexts on one GPU: how a one-GPU box exercises this)."""
+
+    def __init__(self, fs, threshold, devices=(0,), flags=0, scales=None):
+        self.fs, self.sps = float(fs), int(fs // 1e6)
+        self.contexts = [_native.Context(fs, threshold, device=int(d), flags=int(flags)) for d in devices]
+        for fmt, sc in (scales or {}).items():
+            for cx in self.contexts:
+                cx.set_format_scale(fmt, sc)
+        self.last_stats = None
+
+    def set_threshold(self, thr):
+        for cx in self.contexts:
+            cx.set_threshold(thr)
+
+    def pinned(self, n_items, dtype):
+        """Page-locked host ring near the FIRST device (one ring feeds every device; on a two-socket node the far socket's
+        GPUs read it over the interconnect -- a caller with one ring per socket makes two MultiDevice objects)."""
+        return _native.PinnedArray(n_items, dtype, near=self.contexts[0])
+
+    def process_host(self, fmt, data, shards_per_device=1, abs_offset=0, out=None):
+        recs, self.last_stats = _native.process_sharded_multi(self.contexts, fmt, data, shards_per_device, abs_offset, out=out,
+                                                              want_stats=True)
+        return recs
+
+    def close(self):
+        for cx in self.contexts:
+            cx.close()
+        self.contexts = []

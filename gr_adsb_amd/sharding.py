@@ -143,3 +143,49 @@ def finish_shard(recs, sps, rank, all_gather_pair, ungated_fn, all_gather_obj, i
     mine = ungated_fn()
     whole = _native.stitch(np.concatenate(all_gather_obj(mine)), sps)
     return whole[np.isin(whole["offset"], mine["offset"])]
+
+
+class ShardedRank:
+    """One rank's side of the N-process deployment (one process per GPU): its overlapped time shard resident in HBM as a
+    torch tensor, `depth` passes in flight; per pass one device pass over the shard, ONE 16-byte exchange of end-of-burst
+    state (all_gather_pair: make_pair_exchange) and the host fix-up of the shard's head (finish_shard) -- no data-path
+    collective.  step() submits the next pass and collects the oldest once `depth` are in flight; drain() collects the rest
+    and returns the number of bursts this rank kept in the last pass; last_kept holds them.
+    (One PROCESS with all the GPUs of a node: frontend.MultiDevice / adsb_process_sharded_multi.)"""
+
+    def __init__(self, fe, iq, plan, stream_len, rank, all_gather_pair, all_gather_obj, depth=_native.MAX_IN_FLIGHT, fmt=_native.FMT_FC32):
+        self.fe, self.iq, self.plan, self.stream_len, self.sps, self.rank = fe, iq, plan, stream_len, fe.sps, rank
+        self.ag_int, self.ag_obj, self.depth, self.fmt = all_gather_pair, all_gather_obj, depth, fmt
+        self.pending, self.stash = [], {}      # tickets in flight; results of tickets collected early (fallback path only)
+        self.last_kept, self.last_n, self.stitch_s, self.passes = None, 0, 0.0, 0
+
+    def step(self):
+        p = self.plan
+        self.pending.append(self.fe.submit_shard_tensor(self.iq, p["lo"], p["own_lo"], p["own_hi"], self.stream_len,
+                                                        fmt=self.fmt, head_cands=HEAD_CANDS))
+        if len(self.pending) == self.depth:
+            self._collect(self.pending.pop(0))
+
+    def drain(self):
+        while self.pending:
+            self._collect(self.pending.pop(0))
+        return self.last_n
+
+    def _ungated(self):
+        # fallback of finish_shard: a blocking call is only allowed with no ticket pending, so collect (and keep)
+        # whatever is still in flight first; every rank takes this path together
+        for t in list(self.pending):
+            self.stash[t] = self.fe.wait(t)
+        p = self.plan
+        return self.fe.shard_tensor(self.iq, p["lo"], p["own_lo"], p["own_hi"], self.stream_len, fmt=self.fmt)
+
+    def _collect(self, ticket):
+        if ticket in self.stash:
+            recs, inplace = self.stash.pop(ticket), False
+        else:
+            recs, inplace = self.fe.wait(ticket, copy=False), True      # view of the pinned result buffer, fixed up in place
+        t_x = time.perf_counter()
+        kept = finish_shard(recs, self.sps, self.rank, self.ag_int, self._ungated, self.ag_obj, inplace=inplace)
+        self.stitch_s += time.perf_counter() - t_x
+        self.passes += 1
+        self.last_kept, self.last_n = kept, len(kept)

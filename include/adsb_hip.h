@@ -16,6 +16,8 @@
  *   adsb_submit_format_host         the same fed from host memory: the SDR source -> framer chain of examples/adsb_rx.py:113-126,180-196
  *   adsb_last_confidence            demod.bit_confidence           python/adsb/demod.py:97-101
  *   adsb_shard_device / adsb_shard_fixup / adsb_stitch   (no reference counterpart: overlapped time shards, host stitch)
+ *   adsb_process_sharded_multi      the single process of examples/adsb_rx.py:242-268 (one flowgraph, one IQ source) fed to
+ *                                   N devices: one host ring in, one stitched burst list out (ABI 5)
  *
  * Conventions: the caller owns every buffer it passes; the library owns device memory, pinned staging
  * and one HIP stream per context.  A context is single-threaded; different contexts may be used
@@ -33,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ADSB_ABI_VERSION 4
+#define ADSB_ABI_VERSION 5
 #define ADSB_MAX_SPS 100 /* highest sample rate accepted: 100 Msps (tested up to and including it against the reference) */
 #ifndef ADSB_MAX_IN_FLIGHT
 #define ADSB_MAX_IN_FLIGHT 3 /* adsb_submit_* calls that may be pending at once */
@@ -158,7 +160,11 @@ int adsb_host_copy(adsb_ctx* ctx, void* dst, const void* src, size_t bytes);
  * queued with that next call, on the stream its first operation runs on (a host-fed submission: the upload stream); a later submission that depends on the same producer asks again.  Up to four events may be pending.  The
  * event must stay alive until that next call has returned. */
 int adsb_wait_for_event(adsb_ctx* ctx, void* hip_event);
-/* Forget the framer's cross-call state (prev_in0 = 0, prev_eob = -1; framer.py:54,57). */
+/* Pending events are consumed by the next call that queues GPU work.  A call that returns before it queues anything (an
+ * argument error, -EBUSY, n == 0, adsb_demod_work without tags) leaves them pending for the call after it -- the events must
+ * stay alive until then, or be dropped with adsb_clear_pending_events (ABI 5; adsb_reset drops them too). */
+int adsb_clear_pending_events(adsb_ctx* ctx);
+/* Forget the framer's cross-call state (prev_in0 = 0, prev_eob = -1; framer.py:54,57) and any pending adsb_wait_for_event. */
 int adsb_reset(adsb_ctx* ctx);
 /* The framer's two words of cross-call state as the reference keeps them on the block (framer.py:54 `prev_in0`, :57
  * `prev_eob_idx`, both public attributes there): what adsb_framer_work carries between calls.  Either pointer may be NULL. */
@@ -302,6 +308,41 @@ int32_t adsb_shard_bounds(int64_t stream_len, int32_t n_shards, int32_t g, int s
  * demod.py:57-136), like adsb_process_format_device; the tiling itself has no reference counterpart. */
 int adsb_process_sharded_device(adsb_ctx* ctx, int format, const void* d_data, int64_t n, int64_t abs_offset,
                                 int32_t shards, adsb_burst* out, int32_t cap, int32_t* n_out);
+/* (d_data: memory the DEVICE can read -- device memory, e.g. adsb_device_alloc below, or page-locked host memory, which the
+ * kernels then read over PCIe.  Every shard pass waits for the events of adsb_wait_for_event.  -EINVAL on an
+ * ADSB_FLAG_CONFIDENCE context: the rows of adsb_last_confidence belong to the records of one pass.) */
+
+/* ONE process, N devices, ONE host ring (ABI 5): the reference is a single process with a single IQ source
+ * (examples/adsb_rx.py:242-268); this is that process with N GPUs behind it.  `host` holds n samples of `format` (page-locked
+ * -- adsb_host_alloc[_near], adsb_host_register: DMA'd where they lie -- or pageable: through each context's staging ring);
+ * ctxs[0..n_ctx) are contexts of the SAME rate, threshold, gate flag and format scale, normally one per device (several on
+ * one device are allowed: that is how a one-GPU box tests it).  The stream is tiled into n_ctx * shards_per_ctx overlapped
+ * time shards (adsb_shard_bounds, align 4096); context k takes shards [k*shards_per_ctx, (k+1)*shards_per_ctx).  Inside the
+ * call one feeder thread per context -- on the cpus local to its GPU, within the process's own mask -- uploads shard i+1
+ * beside the shard pass of i and the record download of i-1 (ADSB_MAX_IN_FLIGHT deep); the calling thread takes finished
+ * shards in stream order, re-gates every head with the end-of-burst state carried over the seam (adsb_shard_fixup) and
+ * appends the kept records to `out`; a head that ends inside a chain of overlapping bursts has its shard run again on its
+ * own context (head 4096, then ungated + the plain greedy gate: exact in every case).  No collective, no second process:
+ * one int64 crosses each seam, on the host.  Result: bit-identical to adsb_process_format over the whole buffer (records,
+ * order, flags except ADSB_BURST_HEAD, cleared).  -ENOSPC with *n_out = the number needed when `out` is too small; on any
+ * other error nothing stays in flight on any context and adsb_last_error(ctxs[0]) names the cause.  stats may be NULL. */
+#define ADSB_MULTI_MAX_CTX 64
+typedef struct adsb_multi_stats {
+  int32_t contexts, shards, fallbacks, pad_;
+  double wall_s;                         /* the whole call */
+  double feeder_s[ADSB_MULTI_MAX_CTX];   /* context k's feeder thread: first upload queued -> last shard collected */
+  int32_t device[ADSB_MULTI_MAX_CTX];    /* HIP ordinal of context k */
+  int32_t numa_node[ADSB_MULTI_MAX_CTX]; /* NUMA node its pinned buffers and feeder live on (-1: unknown / not bound) */
+} adsb_multi_stats;
+int adsb_process_sharded_multi(adsb_ctx* const* ctxs, int32_t n_ctx, int format, const void* host, int64_t n,
+                               int64_t abs_offset, int32_t shards_per_ctx, adsb_burst* out, int32_t cap, int32_t* n_out,
+                               adsb_multi_stats* stats);
+/* Device memory on the context's device for callers that do not link HIP (a C or ctypes client of the *_device entry
+ * points): hipMalloc / hipFree / a blocking hipMemcpy host -> device.  16-byte alignment is guaranteed.  No reference
+ * counterpart (the reference never leaves host memory). */
+int adsb_device_alloc(adsb_ctx* ctx, void** d, size_t bytes);
+int adsb_device_free(adsb_ctx* ctx, void* d);
+int adsb_device_upload(adsb_ctx* ctx, void* d, const void* host, size_t bytes);
 /* eob_in = (offset of the last burst kept before this shard) + 63*sps, or a very negative number for the
  * first shard.  Compacts recs in place to the exact kept list; -EAGAIN if the head region was too short
  * (call adsb_shard_device again with a larger head_cands, or with 0 and adsb_stitch). */

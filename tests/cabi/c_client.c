@@ -101,16 +101,19 @@ int main(int argc, char** argv) {
     }
     free(got2);
   }
-  /* ABI 4: the stream as overlapped time shards, planned, pipelined and stitched inside the library (one C call).  The
-   * page-locked buffer is device-visible under its host address (hipHostMalloc), so it serves as the "device" input here:
-   * 1, 3 and 7 shards, each identical to the blocking result; the tiling itself (adsb_shard_bounds) covers the stream. */
+  /* ABI 4: the stream as overlapped time shards, planned, pipelined and stitched inside the library (one C call), from a
+   * DEVICE-resident copy of the stream (ABI 5: adsb_device_alloc / _upload -- this client does not link HIP): 1, 3 and 7
+   * shards, each identical to the blocking result; the tiling itself (adsb_shard_bounds) covers the stream. */
   if (n >= 4096) {
     adsb_burst* got3 = (adsb_burst*)calloc((size_t)nwant + 1, sizeof(adsb_burst));
+    void* d_iq = NULL;
+    if (adsb_device_alloc(c, &d_iq, nb) != 0 || !d_iq || ((size_t)d_iq & 15u) || adsb_device_upload(c, d_iq, iq, nb) != 0) bad = 1;
+    if (adsb_device_alloc(c, NULL, nb) != -EINVAL || adsb_device_upload(c, NULL, iq, nb) != -EINVAL) bad = 1;
     const int32_t shard_counts[3] = {1, 3, 7};
     for (int k = 0; k < 3 && !bad; ++k) {
       int32_t m = -1;
       const int32_t S = shard_counts[k];
-      if (adsb_process_sharded_device(c, ADSB_FMT_FC32, pinned, n, 0, S, got3, nwant + 1, &m) != 0 || m != nwant) { bad = 1; break; }
+      if (adsb_process_sharded_device(c, ADSB_FMT_FC32, d_iq, n, 0, S, got3, nwant + 1, &m) != 0 || m != nwant) { bad = 1; break; }
       for (int32_t i = 0; i < nwant && !bad; ++i)
         bad = got3[i].offset != got[i].offset || memcmp(got3[i].bits, got[i].bits, 14) || memcmp(&got3[i].peak, &got[i].peak, 8) ||
               ((got3[i].flags ^ got[i].flags) & (uint16_t)~ADSB_BURST_HEAD);
@@ -123,8 +126,38 @@ int main(int argc, char** argv) {
       if (!bad && prev_hi != n) bad = 1;
     }
     int32_t m0 = -1;
-    if (!bad && nwant > 1 && (adsb_process_sharded_device(c, ADSB_FMT_FC32, pinned, n, 0, 3, got3, 1, &m0) != -ENOSPC || m0 != nwant)) bad = 1;
-    if (!bad && adsb_process_sharded_device(c, ADSB_FMT_FC32, pinned, n, 0, 0, got3, nwant + 1, &m0) != -EINVAL) bad = 1;
+    if (!bad && nwant > 1 && (adsb_process_sharded_device(c, ADSB_FMT_FC32, d_iq, n, 0, 3, got3, 1, &m0) != -ENOSPC || m0 != nwant)) bad = 1;
+    if (!bad && adsb_process_sharded_device(c, ADSB_FMT_FC32, d_iq, n, 0, 0, got3, nwant + 1, &m0) != -EINVAL) bad = 1;
+    if (adsb_device_free(c, d_iq) != 0 || adsb_device_free(c, NULL) != 0) bad = 1;
+
+    /* ABI 5: one process, N contexts (here: three on device 0 -- on an 8-GPU node one per device), ONE host buffer, one
+     * stitched list: adsb_process_sharded_multi, from the page-locked copy and from the pageable one, 1 and 2 shards per
+     * context; identical to the blocking result every time */
+    {
+      adsb_ctx* cs[3] = {c, NULL, NULL};
+      if (adsb_create(fs, thr, 0, 0, &cs[1]) != 0 || adsb_create(fs, thr, 0, 0, &cs[2]) != 0) bad = 1;
+      for (int nc = 1; nc <= 3 && !bad; nc += 2) {
+        for (int spc = 1; spc <= 2 && !bad; ++spc) {
+          const void* src = (spc == 1) ? (const void*)pinned : (const void*)iq;
+          adsb_multi_stats ms;
+          int32_t m = -1;
+          memset(got3, 0, ((size_t)nwant + 1) * sizeof(adsb_burst));
+          const int r = adsb_process_sharded_multi((adsb_ctx* const*)cs, nc, ADSB_FMT_FC32, src, n, 0, spc, got3, nwant + 1, &m, &ms);
+          if (r != 0 || m != nwant || ms.contexts != nc || ms.shards != nc * spc || !(ms.wall_s > 0)) { fprintf(stderr, "multi: rc %d n %d (%s)\n", r, m, adsb_last_error(c)); bad = 1; break; }
+          for (int32_t i = 0; i < nwant && !bad; ++i)
+            bad = got3[i].offset != got[i].offset || memcmp(got3[i].bits, got[i].bits, 14) || memcmp(&got3[i].peak, &got[i].peak, 8) ||
+                  ((got3[i].flags ^ got[i].flags) & (uint16_t)~ADSB_BURST_HEAD);
+        }
+      }
+      if (!bad && nwant > 1 && (adsb_process_sharded_multi((adsb_ctx* const*)cs, 3, ADSB_FMT_FC32, pinned, n, 0, 1, got3, 1, &m0, NULL) != -ENOSPC || m0 != nwant)) bad = 1;
+      adsb_ctx* const c2 = cs[2];
+      cs[2] = cs[1];   /* a context listed twice */
+      if (!bad && adsb_process_sharded_multi((adsb_ctx* const*)cs, 3, ADSB_FMT_FC32, pinned, n, 0, 1, got3, nwant + 1, &m0, NULL) != -EINVAL) bad = 1;
+      cs[2] = NULL;
+      if (!bad && adsb_process_sharded_multi((adsb_ctx* const*)cs, 3, ADSB_FMT_FC32, pinned, n, 0, 1, got3, nwant + 1, &m0, NULL) != -EINVAL) bad = 1;
+      adsb_destroy(cs[1]);
+      adsb_destroy(c2);
+    }
     free(got3);
   }
   /* opt-in confidence ratios (demod.py:97-101): a context without the flag refuses, one with it returns n x 112 floats

@@ -221,21 +221,24 @@ def preamble_train_iq(n, spacing=32, sps=2, seed=3):
     return iq
 
 
-def rise_storm_iq8(n, seed=0, offset_binary=False, hi=100, lo=2):
+def rise_storm_iq8(n, seed=0, offset_binary=False, hi=100, lo=2, half=1):
     """Interleaved 8-bit IQ (2n values) whose |IQ|^2 crosses a threshold of 0.01 (scale 1/128) up to 512 times per 1024-sample
-    tile: 16-sample blocks that are either alternating high / low (8 rises), a bare preamble pattern at half-chip spacing 1
-    (chips 0, 2, 7, 9 high: 4 rises, the first one a matched centre at 2 Msps) or quiet -- more rises per tile than the 8-bit
-    formats' rise list holds (256), with matched preambles in every part of the tile, so the batches of k_detect's B.1 loop
-    are exercised and their hits must come out in stream order."""
+    tile: blocks of 16 * half samples that are either alternating high / low sample by sample (8 * half rises), a bare
+    preamble pattern at `half` samples per chip (chips 0, 2, 7, 9 high: 4 rises, the first one a matched centre at
+    2 * half Msps) or quiet -- more rises per tile than the 8-bit formats' rise list holds (256), with matched preambles in
+    every part of the tile, so the batches of k_detect's B.1 loop are exercised and their hits must come out in stream order.
+    half = 1 (2 Msps) is the generator of round 5 bit for bit."""
     rng = np.random.default_rng(seed)
-    nb = n // 16
+    B = 16 * half
+    nb = n // B
     kind = rng.choice(3, size=nb, p=[0.6, 0.3, 0.1])
     i = np.full(n, lo, dtype=np.int16)
-    alt = np.zeros(16, dtype=np.int16)
+    alt = np.zeros(B, dtype=np.int16)
     alt[0::2] = hi - lo
-    pre = np.zeros(16, dtype=np.int16)
-    pre[[0, 2, 7, 9]] = hi - lo
-    blocks = i[:nb * 16].reshape(nb, 16)
+    pre = np.zeros(B, dtype=np.int16)
+    for c in (0, 2, 7, 9):
+        pre[c * half:(c + 1) * half] = hi - lo
+    blocks = i[:nb * B].reshape(nb, B)
     blocks[kind == 0] += alt
     blocks[kind == 1] += pre
     blocks += rng.integers(0, 3, size=blocks.shape, dtype=np.int16) * (blocks > lo)        # unequal peaks: medians / SNR vary

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(native):
     for n in names:
         assert hasattr(lib, n), "missing export " + n
     assert set(names) == set(native.EXPORTS)
-    assert lib.adsb_abi_version() == native.ABI_VERSION == 4
+    assert lib.adsb_abi_version() == native.ABI_VERSION == 5
 
 
 def test_struct_layouts(native):

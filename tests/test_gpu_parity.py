@@ -242,12 +242,14 @@ def test_every_rise_a_tile_can_have_8bit_formats(native, torch_mod, fmt_name, sc
     from oracle import adsb_oracle as O
     from oracle import c_oracle as C
     fmt = native.FMT_SC8 if fmt_name == "sc8" else native.FMT_CU8
-    n, sps = (1 << 20) + 77, int(fs // 1e6)
-    q = rise_storm_iq8(n, seed=int(fs // 1e6), offset_binary=fmt_name == "cu8")
+    sps = int(fs // 1e6)
+    n = (1 << 20) * max(1, sps // 4) + 77          # (the gate holds 63 * sps samples: longer streams at the higher rates)
+    # (the blocks' bare preambles are spaced for THIS rate -- sps / 2 samples per chip -- so the one-wavefront path meets matched
+    # centres among its rise storm at 6 and 8 Msps too, not only rises)
+    q = rise_storm_iq8(n, seed=int(fs // 1e6), offset_binary=fmt_name == "cu8", half=sps // 2)
     x = O.mag2_iq8(q, float(np.float32(scale)), fmt_name == "cu8")
     want = C.canonical(x, sps, np.float32(0.01))
-    if sps == 2:                                   # (the blocks' bare preambles are spaced for 2 Msps; at other rates: rises only)
-        assert len(want) > 2000
+    assert len(want) > 2000, len(want)
     ctx = native.Context(fs, 0.01)
     ctx.set_format_scale(fmt, scale)
     assert_recs_equal(ctx.process_format(fmt, q), want, "rise storm %s %g %g" % (fmt_name, scale, fs))

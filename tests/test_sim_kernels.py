@@ -593,3 +593,11 @@ def test_every_rise_a_tile_can_have_8bit_formats(mode, scale, fs):
                 t0 = -(8 * sps - 1) + ((int(off) + 8 * sps - 1) // 1024) * 1024
                 late += int(np.count_nonzero((ridx >= t0) & (ridx < off)) >= 256)
             assert late >= 1, "no burst behind the 256th rise of a tile"
+        else:
+            # the same storm with the bare preambles spaced for THIS rate: matched centres among the rises at 4 and 6 Msps too
+            q = rise_storm_iq8(n, seed=seed, offset_binary=mode == 4, half=sps // 2)
+            x = O.mag2_iq8(q, float(np.float32(scale)), mode == 4)
+            want = C.canonical(x, sps, np.float32(0.01))
+            assert len(want) >= 3
+            recs, so = simlib.sim_canonical(mode, q, fs, 0.01, scale=float(np.float32(scale)))
+            assert_recs_equal(recs, want, "rise storm spaced for the rate, mode %d scale %g fs %g seed %d" % (mode, scale, fs, seed))

@@ -44,7 +44,7 @@ EXPORTS = [
     "adsb_set_iq16_scale", "adsb_process_iq16", "adsb_process_iq16_device",
     "adsb_set_format_scale", "adsb_process_format", "adsb_process_format_device", "adsb_submit_format_device",
     "adsb_submit_format_host", "adsb_last_confidence",
-    "adsb_framer_work", "adsb_demod_work", "adsb_shard_bounds", "adsb_process_sharded_device", "adsb_shard_device", "adsb_shard_host", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_mode_s_syndrome", "adsb_plan_chunks", "adsb_get_stats",
+    "adsb_framer_work", "adsb_framer_work_passthrough", "adsb_demod_work", "adsb_shard_bounds", "adsb_process_sharded_device", "adsb_shard_device", "adsb_shard_host", "adsb_shard_fixup", "adsb_stitch", "adsb_snr_db", "adsb_mode_s_syndrome", "adsb_plan_chunks", "adsb_get_stats",
     "adsb_process_sharded_multi", "adsb_device_alloc", "adsb_device_free", "adsb_device_upload", "adsb_clear_pending_events",
     "adsb_reset_stats", "adsb_detect_history", "adsb_numa_info", "adsb_host_alloc_near", "adsb_last_error", "adsb_host_alloc", "adsb_host_free", "adsb_host_register", "adsb_host_unregister",
 ]
@@ -125,6 +125,7 @@ def load():
     lib.adsb_wait.argtypes = [vp, i32, vp, i32, c.POINTER(i32)]
     lib.adsb_submit_shard_device.argtypes = [vp, c.c_int, vp, i64, i64, i64, i64, i64, i32, c.POINTER(i32)]
     lib.adsb_framer_work.argtypes = [vp, vp, i64, i64, i64, vp, i32, c.POINTER(i32)]
+    lib.adsb_framer_work_passthrough.argtypes = [vp, vp, i64, i64, i64, vp, vp, i32, c.POINTER(i32)]
     lib.adsb_demod_work.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp, vp]
     lib.adsb_shard_device.argtypes = [vp, c.c_int, vp, i64, i64, i64, i64, i64, i32, vp, i32, c.POINTER(i32)]
     lib.adsb_shard_host.argtypes = [vp, c.c_int, vp, i64, i64, i64, i64, i64, i32, c.c_uint32, vp, i32, c.POINTER(i32)]
@@ -366,7 +367,9 @@ class Context:
         self._chk(self.lib.adsb_framer_state(self._h, ctypes.byref(p), ctypes.byref(e)))
         return np.float32(p.value), int(e.value)
 
-    def framer_work(self, in0, N, nitems_written):
+    def framer_work(self, in0, N, nitems_written, out0=None):
+        """out0 (optional): the block's pass-through output, float32[N], contiguous -- filled by the library beside the device
+        pass (adsb_framer_work_passthrough)."""
         if in0.dtype != np.float32 or not in0.flags.c_contiguous:
             in0 = np.ascontiguousarray(in0, dtype=np.float32)
         buf = getattr(self, "_tag_buf", None)
@@ -374,8 +377,13 @@ class Context:
             buf = self._tag_buf = np.zeros(512, dtype=BURST_DTYPE)     # tags of one work() call, filled by the library
             self._tag_n = ctypes.c_int32(0)
             self._tag_ptr = ctypes.c_void_p(buf.ctypes.data)
-        rc = self.lib.adsb_framer_work(self._h, ctypes.c_void_p(in0.ctypes.data), len(in0), int(N), int(nitems_written),
-                                       self._tag_ptr, len(buf), ctypes.byref(self._tag_n))
+        if out0 is not None:
+            assert out0.dtype == np.float32 and out0.flags.c_contiguous and len(out0) == N
+            rc = self.lib.adsb_framer_work_passthrough(self._h, ctypes.c_void_p(in0.ctypes.data), len(in0), int(N), int(nitems_written),
+                                                       ctypes.c_void_p(out0.ctypes.data), self._tag_ptr, len(buf), ctypes.byref(self._tag_n))
+        else:
+            rc = self.lib.adsb_framer_work(self._h, ctypes.c_void_p(in0.ctypes.data), len(in0), int(N), int(nitems_written),
+                                           self._tag_ptr, len(buf), ctypes.byref(self._tag_n))
         if rc == -28:                                                  # -ENOSPC: more tags than the buffer holds
             return self.last_result()
         self._chk(rc)

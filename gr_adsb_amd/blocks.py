@@ -237,7 +237,9 @@ class framer(gr.sync_block):
         self._ctx.set_threshold_cached(self.threshold)
         if self.improved:
             return self._work_improved(in0, out0)
-        bursts = self._ctx.framer_work(in0[:N + self.N_hist - 1], N, self.nitems_written(0))
+        # chunks of 256 KiB and more: the pass-through copy (framer.py:181) runs inside the library beside the device pass
+        fused_copy = out0.nbytes >= _FUSE_COPY_BYTES and out0.flags.c_contiguous and out0.dtype == np.float32
+        bursts = self._ctx.framer_work(in0[:N + self.N_hist - 1], N, self.nitems_written(0), out0=out0 if fused_copy else None)
         nb = len(bursts)
         if nb:                                            # (most scheduler-sized work() calls carry no burst)
             key, src, add, to_pmt = self._pmt_key, self._pmt_src, self.add_item_tag, pmt.to_pmt
@@ -270,13 +272,17 @@ class framer(gr.sync_block):
                         self._slices.put(bursts["offset"][dem], bursts["bits"][dem], fl[dem])
                 for off, s_ in zip(bursts["offset"].tolist(), snr.tolist() if HAVE_GNURADIO else list(snr)):
                     add(0, off, key, to_pmt(("SOB", s_)), src)
-        _passthrough(self._ctx, out0, in0[self.N_hist - 1:])
+        if not fused_copy:
+            _passthrough(self._ctx, out0, in0[self.N_hist - 1:])
         return N
 
 
+_FUSE_COPY_BYTES = 256 << 10
+
+
 def _passthrough(ctx, out0, src):
-    """out0[:] = src (framer.py:181, demod.py:135); multi-megabyte chunks through the library's copy threads."""
-    if out0.nbytes >= (4 << 20) and out0.flags.c_contiguous and src.flags.c_contiguous and src.dtype == out0.dtype:
+    """out0[:] = src (framer.py:181, demod.py:135); chunks of a megabyte and more through the library's copy threads."""
+    if out0.nbytes >= (1 << 20) and out0.flags.c_contiguous and src.flags.c_contiguous and src.dtype == out0.dtype:
         ctx.host_copy(out0, src)
     else:
         out0[:] = src

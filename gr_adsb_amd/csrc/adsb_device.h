@@ -36,6 +36,7 @@
 // kernels run on a machine without a GPU.
 #pragma once
 
+
 namespace adsb {
 
 constexpr int kThreads = 256;            // 4 wavefronts per workgroup: the tail kernels and the one-launch small pass
@@ -369,6 +370,7 @@ __device__ __forceinline__ BurstFetch<MODE> burst_issue(const DetectArgs& a, uns
 // np.median of the noise window held by a wavefront (framer.py:156-159): lane l has window samples l and l + 64 (v0, v1;
 // valid iff val0, val1; nwin = window length).  Wave-uniform result.  `hint` (wave-uniform, in and out): the key this
 // function found for the wavefront's previous burst, 0 = none -- a first guess that is proved before it is used.
+template <bool QUANT = false>
 __device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, float v0, float v1, unsigned& hint) {
   const unsigned long long nanm = __ballot((val0 && v0 != v0) || (val1 && v1 != v1));
   const unsigned k0 = val0 ? f32_key(v0) : 0xFFFFFFFFu;      // lanes outside the window sort last
@@ -393,6 +395,18 @@ __device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, fl
   // costs its two counts and the search starts from the full range), and replace the first nine steps.
   const unsigned h = (unsigned)adsb_uniform((int)hint);
   bool full = true;
+  // QUANT (streams quantised to a few levels: the 8-bit formats): the noise floor of consecutive bursts has, more often than
+  // not, the very SAME median value.  Two counts prove it -- at most kt keys below h, more than kt keys not above it: h IS the
+  // key of rank kt -- and the second one also answers the even window's question (does the value occur again above rank
+  // kt?).  A hint that fails costs those two counts; the search below then starts as it always did.
+  bool exact = false, exact_again = false;
+  if (QUANT && h >= 0x00800000u && h < 0xFF000000u) {
+    const int c_lt = below(h), c_le = below(h + 1u);
+    if (c_lt <= kt && c_le > kt) { exact = true; exact_again = c_le >= kt + 2; }
+  }
+  if (exact) {
+    A = h; have = true; full = false;
+  } else
   if (h >= 0x00800000u && h < 0xFF000000u) {                 // wave-uniform; h +- 2^23 cannot wrap
     const int c1 = below(h);                                   // <= kt: the key is >= h
     const unsigned T2 = c1 <= kt ? h + 0x00800000u : h - 0x00800000u;
@@ -409,6 +423,7 @@ __device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, fl
       if (below(T) <= kt) lo = T;
     }
   }
+  if (!exact) {
 #pragma unroll
   for (int b = 22; b >= 20; --b) {                           // the key lies in [lo, lo + 2^(b+1)); lo need not be aligned
     const unsigned T = lo + (1u << b);
@@ -434,6 +449,7 @@ __device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, fl
       }
     }
   }
+  }
   if (single) {                                              // wave-uniform: fetch the one key inside [lo, lo + span)
     const unsigned long long m0 = __ballot(k0 - lo < span), m1 = __ballot(k1 - lo < span);
     const unsigned a0 = (unsigned)adsb_readlane((int)k0, m0 ? __builtin_ctzll(m0) : 0);
@@ -454,7 +470,8 @@ __device__ __forceinline__ float noise_median(int nwin, bool val0, bool val1, fl
     // upper middle: A again if it occurs often enough (impossible when A was alone in its interval), else the
     // smallest key above A
     bool again = false;
-    if (!single) again = __popcll(__ballot(k0 <= A)) + __popcll(__ballot(k1 <= A)) >= kt + 2;
+    if (exact) again = exact_again;
+    else if (!single) again = __popcll(__ballot(k0 <= A)) + __popcll(__ballot(k1 <= A)) >= kt + 2;
     unsigned B = A;
     if (!again) {                                            // wave-uniform
       unsigned m = (k0 > A) ? k0 : 0xFFFFFFFFu;
@@ -627,7 +644,7 @@ __device__ __forceinline__ void burst_from_window(WinArgs<CP> a, const float* s_
   const float v0 = val0 ? s_x[wl + lane] : 0.0f;
   const float v1 = val1 ? s_x[wl + lane + 64] : 0.0f;
   const float peak = s_x[p];
-  const float med = noise_median(nwin, val0, val1, v0, v1, med_hint);
+  const float med = noise_median<mode_is_iq8(MODE)>(nwin, val0, val1, v0, v1, med_hint);
   rec_store_head(out, a.origin + P, peak, med, lane);
   const unsigned flags = (dem ? kDemod : 0u) | xflags;
   unsigned long long ma = 0ull, mb = 0ull;
@@ -765,9 +782,11 @@ __device__ __forceinline__ void pend_flush(const PendList* pend, int n_pend, Win
 //   * commit: 16-byte loads one tile ahead -> |IQ|^2 -> LDS, and the running integer maximum of the bit patterns (one
 //     v_max3 per two samples).  A body whose maximum stays below the threshold's bit pattern ("quiet": half of the
 //     tiles at 1 k bursts/s) costs nothing more than a zero written to its mask units.
-//   * only an active body pays for its threshold masks: lane l reads its 16 consecutive floats back from LDS and builds
-//     its own 16-bit mask (adsb_above4: compare + add-with-carry, 2 instructions per sample) -- mask unit u covers
-//     samples [16u, 16u+16) of the window; units are 16-bit halves of the dwords the fall search reads.
+//   * only an active body pays for its threshold masks (adsb_above4: compare + add-with-carry, 2 instructions per sample)
+//     -- mask unit u covers samples [16u, 16u+16) of the window; units are 16-bit halves of the dwords the fall search
+//     reads.  The 8-bit formats build them in body_commit from the registers that still hold the converted samples (a
+//     lane's load holds eight consecutive samples = one mask byte; round 6); the other formats' lanes read their 16
+//     consecutive floats back from LDS (unit_mask).
 //   * rises by 16-bit mask algebra per lane, the ordered rise list by a DPP prefix sum and a short per-lane loop that
 //     stores positions only; fall, centre and the 16 chip taps per rise with one lane per rise.
 //   * the tile counter and every per-tile condition are 32-bit scalars computed once per unit.
@@ -778,6 +797,7 @@ constexpr int kHeadUnits = kFwd / kUnit;         // 16 units of forward halo
 constexpr int kMaskDwords = kUnits / 2;          // the same masks read as 32-bit words
 static_assert(kTileUnits == 64 && kUnits % 2 == 0 && kFwd == 256 && kBack == 128, "lane <-> unit mapping and the slide copies");
 typedef unsigned short __attribute__((may_alias)) u16_alias;
+typedef unsigned char __attribute__((may_alias)) u8_alias;
 typedef unsigned __attribute__((may_alias)) u32_alias;
 
 // entries of the per-tile hit list (16 bits, written over the rise list in place)
@@ -854,8 +874,15 @@ __device__ __forceinline__ void body_convert(const float4& q, float scale, float
 // integers; a NaN with the sign clear is larger than everything and only sends the body down the exact path).
 // REISSUE: every register is loaded again from `next` (this wavefront's next body, entirely inside the buffer) the
 // moment its samples have been converted.
-template <int MODE, bool REISSUE>
-__device__ __forceinline__ int body_commit(Body<MODE>& b, float* sx_body, float scale, int lane, const char* next) {
+// MASKS (the 8-bit formats: a lane's load holds EIGHT consecutive samples): when the body is active -- some lane's maximum
+// reaches thr_bits, or !thr_pos -- the threshold masks of the lane's 2 x 8 samples are built right here from the registers
+// (*bm = mask byte of load 0 | mask byte of load 1 << 8; mask byte k covers body samples [512 k + 8 lane, + 8)) instead of
+// from floats read back from LDS (unit_mask: four ds_read_b128 at a 64-byte lane stride = 4-way bank conflicts, and a
+// round trip through the LDS in the middle of every active tile); *active tells which.
+template <int MODE, bool REISSUE, bool MASKS = false>
+__device__ __forceinline__ int body_commit(Body<MODE>& b, float* sx_body, float scale, int lane, const char* next,
+                                           float thr = 0.0f, int thr_bits = 0, bool thr_pos = true, unsigned* bm = nullptr,
+                                           bool* active = nullptr) {
   using B = Body<MODE>;
   int mx = (int)0x80000000u;
   const unsigned lo = (unsigned)lane * 16u;
@@ -885,6 +912,20 @@ __device__ __forceinline__ int body_commit(Body<MODE>& b, float* sx_body, float 
         mx = imax3(mx, __builtin_bit_cast(int, m[k][j + 2]), __builtin_bit_cast(int, m[k][j + 3]));
       }
     }
+  }
+  if constexpr (MASKS) {
+    static_assert(B::SPL == 8 && B::ITER == 2, "mask bytes from registers: eight consecutive samples per lane and load");
+    const bool act = !thr_pos || __ballot(mx >= thr_bits) != 0ull;      // wave-uniform
+    unsigned v = 0u;
+    if (act) {
+      unsigned a0 = adsb_above4(0u, m[0][7], m[0][6], m[0][5], m[0][4], thr);
+      a0 = adsb_above4(a0, m[0][3], m[0][2], m[0][1], m[0][0], thr);
+      unsigned a1 = adsb_above4(0u, m[1][7], m[1][6], m[1][5], m[1][4], thr);
+      a1 = adsb_above4(a1, m[1][3], m[1][2], m[1][1], m[1][0], thr);
+      v = a0 | (a1 << 8);
+    }
+    *bm = v;
+    *active = act;
   }
   return mx;
 }
@@ -1135,12 +1176,22 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
 
   // Everything a tile needs once its body is in the window (floats at s_x[kFwd ..)): mask units, pending bursts, rises,
   // hits, records, the slide.  One body of code, used by the streaming loop and by the loop for tiny inputs below.
-  auto process_tile = [&](const int it, const long long t0, const bool active, const int lane) {
+  // from_regs: the body's mask bytes come with the call (bm_regs, built by body_commit from the registers: 8-bit formats);
+  // else lane l builds the mask of body unit l from the floats in the window
+  auto process_tile = [&](const int it, const long long t0, const bool active, const int lane, auto from_regs_c, const unsigned bm_regs) {
+    constexpr bool from_regs = decltype(from_regs_c)::value;
     adsb_wave_sync();
-    // mask units of the body (units kHeadUnits .. kUnits): lane l owns body unit l
-    unsigned bm = 0u;
-    if (active) bm = unit_mask(s_x + kFwd + kUnit * lane, thr);      // wave-uniform branch
-    s_m16[kHeadUnits + lane] = (unsigned short)bm;
+    if constexpr (from_regs) {
+      // mask byte k of lane l covers body samples [512 k + 8 l, + 8): byte 2 * kHeadUnits + 64 k + l of the mask array
+      u8_alias* s_m8 = reinterpret_cast<u8_alias*>(s_ma[wave]);
+      s_m8[2 * kHeadUnits + lane] = (unsigned char)bm_regs;
+      s_m8[2 * kHeadUnits + 64 + lane] = (unsigned char)(bm_regs >> 8);
+    } else {
+      // mask units of the body (units kHeadUnits .. kUnits): lane l owns body unit l
+      unsigned bm = 0u;
+      if (active) bm = unit_mask(s_x + kFwd + kUnit * lane, thr);      // wave-uniform branch
+      s_m16[kHeadUnits + lane] = (unsigned short)bm;
+    }
     adsb_wave_sync();
     // -- P: bursts met in earlier tiles take the bit samples that have arrived with this body
     if (n_pend > 0) pend_step<STAGED>(pend, &n_pend, s_x, st, a.sps, half, lane);
@@ -1247,15 +1298,20 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
       const int lane = adsb_opaque(lane_outer);
       const long long t0 = c0 + (long long)it * kWTile;        // (only the rare paths use it)
       nb += (long long)kWTile * BPS;                           // now: the body of tile it + D, which these registers hold next
-      const int mx = body_commit<MODE, true>(b, s_x + kFwd, a.scale, lane, it + D - 1 < it_re ? nb : clamp);
+      constexpr bool MASKS = mode_is_iq8(MODE);
+      unsigned bm_regs = 0u;
+      bool active = false;
+      const int mx = body_commit<MODE, true, MASKS>(b, s_x + kFwd, a.scale, lane, it + D - 1 < it_re ? nb : clamp, thr, thr_bits,
+                                                    thr_pos, &bm_regs, &active);
       if (real) {
-        bool active = !thr_pos || __ballot(mx >= thr_bits) != 0ull;
+        if constexpr (!MASKS) active = !thr_pos || __ballot(mx >= thr_bits) != 0ull;
         if (it >= it_rag) {
           adsb_wave_sync();                                    // every lane's commit stores lie in front of the rewrite below
           for (int i = lane; i < kWTile; i += 64) s_x[kFwd + i] = xg<MODE>(cold()->data, cold()->n, t0 + kFwd + i, a.scale);
-          active = true;
+          process_tile(it, t0, true, lane, BoolC<false>{}, 0u);        // (rare: at most two tiles per launch; masks from the window)
+        } else {
+          process_tile(it, t0, active, lane, BoolC<MASKS>{}, bm_regs);
         }
-        process_tile(it, t0, active, lane);
       }
     };
     // A chunk with a number of tiles that is not a multiple of D ends inside the unrolled body: the steps past its end still
@@ -1275,7 +1331,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
       const int lane = adsb_opaque(lane_outer);
       const long long t0 = c0 + (long long)it * kWTile;
       for (int i = lane; i < kWTile; i += 64) s_x[kFwd + i] = xg<MODE>(cold()->data, cold()->n, t0 + kFwd + i, a.scale);
-      process_tile(it, t0, true, lane);
+      process_tile(it, t0, true, lane, BoolC<false>{}, 0u);
     }
   }
   // what the stage still holds (the whole list of a usual chunk): to global memory, in one go

@@ -939,11 +939,15 @@ int ensure_pool(adsb_ctx* c) {
 // Pageable host memory -> device memory on `stream` through the ring of pinned chunks: the host copy of chunk k+1 (split
 // over the context's copy threads) runs beside the DMA of chunk k.  Returns once the last DMA is QUEUED.
 int staged_copy(adsb_ctx* c, void* d_dst, const void* host, size_t bytes, hipStream_t stream) {
-  constexpr size_t kChunk = (size_t)16 << 20;
+  constexpr size_t kRingChunk = (size_t)16 << 20;
   for (void*& r : c->h_ring)
-    if (!r) HIPCHK(c, host_alloc_near(c, &r, kChunk));          // the staging ring: on the GPU's NUMA node
+    if (!r) HIPCHK(c, host_alloc_near(c, &r, kRingChunk));      // the staging ring: on the GPU's NUMA node
   int rc = ensure_pool(c);
   if (rc) return rc;
+  // the host copy of piece k+1 runs beside the DMA of piece k: a source of a few megabytes (a GNU Radio work() call of a
+  // megasample) is cut into at least four pieces, a bulk one into whole 16 MiB ring chunks
+  size_t kChunk = kRingChunk;
+  while (kChunk > ((size_t)1 << 20) && bytes < 4 * kChunk) kChunk >>= 1;
   for (size_t off = 0; off < bytes; off += kChunk) {
     const size_t m = bytes - off < kChunk ? bytes - off : kChunk;
     const int b = (int)(c->ring_k++ % (unsigned)adsb_ctx::kRing);
@@ -1368,6 +1372,11 @@ int adsb_last_result(adsb_ctx* c, const adsb_burst** bursts, int32_t* n) {
 
 int adsb_framer_work(adsb_ctx* c, const float* in0, int64_t n_in0, int64_t N, int64_t nitems_written,
                      adsb_burst* tags, int32_t cap, int32_t* n_out) {
+  return adsb_framer_work_passthrough(c, in0, n_in0, N, nitems_written, nullptr, tags, cap, n_out);
+}
+
+int adsb_framer_work_passthrough(adsb_ctx* c, const float* in0, int64_t n_in0, int64_t N, int64_t nitems_written, float* out0,
+                                 adsb_burst* tags, int32_t cap, int32_t* n_out) {
   if (!c || !in0 || N < 1) return -EINVAL;
   const long long H = 8ll * c->sps;
   if (n_in0 != N + H - 1) return fail(c, -EINVAL, "framer input must hold N + 8*sps - 1 items");
@@ -1379,7 +1388,21 @@ int adsb_framer_work(adsb_ctx* c, const float* in0, int64_t n_in0, int64_t N, in
   if (c->flags & ADSB_FLAG_FRAMER_SLICES) pl.dem_hi = n_in0;   // bursts that end inside this call's input get their bits
   Summary s;
   int32_t nres = 0;
-  rc = run_pipeline(c, pl, &s, &nres);
+  for (const Slot& sl : c->slot) if (sl.busy) return fail(c, -EBUSY, "a submitted call is still pending (adsb_wait first)");
+  {
+    // the device pass is queued, THEN the block's pass-through copy (framer.py:181: out0[:] = in0[history:]) runs on the
+    // host -- beside the upload's DMA and the kernels instead of behind them -- then the pass is waited for
+    Slot& sl0 = c->slot[0];
+    c->last_slot = 0;
+    rc = enqueue(c, sl0, pl, false);
+    if (rc) { sl0.busy = false; return rc; }
+    if (out0) {
+      const size_t pb = (size_t)N * sizeof(float);
+      if (pb >= ((size_t)1 << 20) && ensure_pool(c) == 0) c->pool->copy((char*)out0, (const char*)(in0 + (H - 1)), pb);
+      else memcpy(out0, in0 + (H - 1), pb);
+    }
+    rc = finish(c, sl0, &s, &nres);
+  }
   if (rc) return rc;
   // cross-call state, exactly as framer.py:87,121-123,165,177-179 (in0 index == local index here)
   framer_state_update(c->st, in0[N - 1], N, c->sps, s.flags, s.lastp, kNoIndex, nres,

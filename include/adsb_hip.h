@@ -256,6 +256,10 @@ int adsb_wait(adsb_ctx* ctx, int32_t ticket, adsb_burst* out, int32_t cap, int32
  * inside ctx exactly like the reference (including its stale-state behaviour, framer.py:177-179). */
 int adsb_framer_work(adsb_ctx* ctx, const float* in0, int64_t n_in0, int64_t N, int64_t nitems_written,
                      adsb_burst* tags, int32_t cap, int32_t* n_out);
+/* The same plus the block's pass-through (framer.py:181 `out0[:] = in0[history:]`): out0 (N floats, may be NULL) is filled
+ * on the host WHILE the device pass runs -- the copy of a multi-megabyte chunk no longer stands behind the pass (ABI 5). */
+int adsb_framer_work_passthrough(adsb_ctx* ctx, const float* in0, int64_t n_in0, int64_t N, int64_t nitems_written, float* out0,
+                                 adsb_burst* tags, int32_t cap, int32_t* n_out);
 
 /* demod.work(): in0 = this call's n input floats, nitems_read = nitems_read(0) (== nitems_written(0)
  * for a sync block); tag_offsets = absolute offsets of the "burst" tags inside [nitems_read,

@@ -27,7 +27,7 @@ def _clear_head(native, recs):
     return r
 
 
-@pytest.mark.parametrize("fs,bps,log2n,seed", [(2e6, 3000, 21, 31), (20e6, 1000, 22, 3), (8e6, 6000, 21, 2), (2e6, -24, 19, 5)])
+@pytest.mark.parametrize("fs,bps,log2n,seed", [(2e6, 3000, 21, 31), (20e6, 1000, 22, 3), (8e6, 6000, 21, 2), (2e6, -32, 19, 5)])
 @pytest.mark.parametrize("n_ctx", [1, 3, 8])
 def test_one_process_n_contexts_equal_one_blocking_call(native, fs, bps, log2n, seed, n_ctx):
     from gr_adsb_amd import modulator as M

@@ -719,6 +719,9 @@ def main():
     ap.add_argument("--low-latency", action="store_true", help="ADSB_FLAG_LOW_LATENCY: tail kernels beside the next pass's k_detect")
     ap.add_argument("--single-stream", action="store_true",
                     help="profiling aid (ADSB_FLAG_SINGLE_STREAM): the sparse tail of a pass behind its k_detect on one stream")
+    ap.add_argument("--sc8-generic", action="store_true",
+                    help="with --format sc8: scale 4/127 instead of 2^-5, i.e. k_detect's generic int8 instance (any scale) instead "
+                         "of the dot-product one (power-of-two scales)")
     ap.add_argument("--format", choices=["fc32", "mag2", "sc16", "sc8", "cu8"], default="fc32",
                     help="input sample format: complex64 (BASELINE workload), float32 |IQ|^2 (the framer's literal input, "
                          "4 B/sample), int16 IQ (4 B/sample) or 8-bit IQ (2 B/sample: int8 / RTL-SDR offset binary); "
@@ -855,7 +858,7 @@ def main():
         iq = gen_stream_blocks(n_own, 0, fs, args.bursts, args.seed, dev, **synth)
         # |IQ|^2 of the same stream (separately rounded products) / the stream quantised to the integer wire
         # format (full scale 4.0; the kernel converts with the same scale), computed once outside the timed region
-        iq = quantise_for(fmt, iq, fe)
+        iq = quantise_for(fmt, iq, fe, scale=4.0 / 127.0 if (args.sc8_generic and args.format == "sc8") else None)
         torch.cuda.synchronize()
         pending = []          # tickets of submitted, not yet collected passes (pipeline of DEPTH passes)
         last_n = [0]
@@ -885,7 +888,8 @@ def main():
         iso_ms = isolated_kernel_ms(fe, fmt, iq, n_own)
         # ... and the same pipeline on a context WITHOUT ADSB_FLAG_TIMING (the product default: no event pair between
         # consecutive k_detect launches), a few repeats right behind the timed ones
-        untimed = untimed_context_ms(args, local_rank, fmt, iq, n_own, DEPTH, sync_all)
+        untimed = untimed_context_ms(args, local_rank, fmt, iq, n_own, DEPTH, sync_all,
+                                     scale=4.0 / 127.0 if (args.sc8_generic and args.format == "sc8") else None)
     else:
         leg = sharded_leg(args, dev, rank, n_gpus, fs, args.bursts, args.seed, n_own, args.steps, args.warmup, args.min_time,
                           DEPTH, sync_all, reduce_max, ag_int, ag_obj, synth, fe=fe,

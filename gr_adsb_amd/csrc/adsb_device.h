@@ -1176,19 +1176,32 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
 
   // Everything a tile needs once its body is in the window (floats at s_x[kFwd ..)): mask units, pending bursts, rises,
   // hits, records, the slide.  One body of code, used by the streaming loop and by the loop for tiny inputs below.
-  // from_regs: the body's mask bytes come with the call (bm_regs, built by body_commit from the registers: 8-bit formats);
-  // else lane l builds the mask of body unit l from the floats in the window
-  auto process_tile = [&](const int it, const long long t0, const bool active, const int lane, auto from_regs_c, const unsigned bm_regs) {
-    constexpr bool from_regs = decltype(from_regs_c)::value;
+  // The body's threshold masks.  MASKS formats (8-bit: mask BYTES, byte k of lane l covers body samples [512 k + 8 l, + 8)):
+  // the streaming loop brings them along (have_bm: built by body_commit from the registers); the rare callers without them
+  // (a tile rewritten by the scalar loop, inputs shorter than a tile) have them built here from the floats in the window,
+  // in the same layout.  Other formats: lane l builds the 16-bit mask of body unit l from the window.
+  auto process_tile = [&](const int it, const long long t0, const bool active, const int lane, const bool have_bm, unsigned bm) {
+    constexpr bool MASKS = mode_is_iq8(MODE);
     adsb_wave_sync();
-    if constexpr (from_regs) {
-      // mask byte k of lane l covers body samples [512 k + 8 l, + 8): byte 2 * kHeadUnits + 64 k + l of the mask array
+    if constexpr (MASKS) {
+      if (!have_bm) {                                                  // wave-uniform
+        bm = 0u;
+        if (active) {
+          const float* q0 = s_x + kFwd + 8 * lane;
+          const float4 a = reinterpret_cast<const float4*>(q0)[0], b = reinterpret_cast<const float4*>(q0)[1];
+          const float4 c = reinterpret_cast<const float4*>(q0 + 512)[0], d = reinterpret_cast<const float4*>(q0 + 512)[1];
+          unsigned m0 = adsb_above4(0u, b.w, b.z, b.y, b.x, thr), m1 = adsb_above4(0u, d.w, d.z, d.y, d.x, thr);
+          m0 = adsb_above4(m0, a.w, a.z, a.y, a.x, thr);
+          m1 = adsb_above4(m1, c.w, c.z, c.y, c.x, thr);
+          bm = m0 | (m1 << 8);
+        }
+      }
       u8_alias* s_m8 = reinterpret_cast<u8_alias*>(s_ma[wave]);
-      s_m8[2 * kHeadUnits + lane] = (unsigned char)bm_regs;
-      s_m8[2 * kHeadUnits + 64 + lane] = (unsigned char)(bm_regs >> 8);
+      s_m8[2 * kHeadUnits + lane] = (unsigned char)bm;
+      s_m8[2 * kHeadUnits + 64 + lane] = (unsigned char)(bm >> 8);
     } else {
       // mask units of the body (units kHeadUnits .. kUnits): lane l owns body unit l
-      unsigned bm = 0u;
+      bm = 0u;
       if (active) bm = unit_mask(s_x + kFwd + kUnit * lane, thr);      // wave-uniform branch
       s_m16[kHeadUnits + lane] = (unsigned short)bm;
     }
@@ -1279,7 +1292,9 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
     // meets a wait for everything at the loop head: round 3's attempt).  Measured with exact waits (round 4,
     // profiles/r04_ab_prefetch_depth.txt): two tiles ahead +2.2 % for int8 IQ with the dot-product conversion (the format
     // with the least arithmetic per byte), +0.8 % int16, 0 for uint8 / |IQ|^2 floats / complex64, three no better than
-    // two -- the narrow formats are NOT short of bytes in flight; kept where it pays for its 50 % more code.
+    // two -- the narrow formats are NOT short of bytes in flight; kept where it pays for its 50 % more code (measured again
+    // in round 6 on the kernels with register-built masks: generic int8 -1 %, uint8 -1.5 % with two tiles ahead:
+    // profiles/r06_ab_8bit_masks_median.txt).
     constexpr int D = (MODE == kModeSc8Pow2) ? 2 : 1;
     Body<MODE> body[D];
     if (ntile > 0) {
@@ -1308,10 +1323,9 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
         if (it >= it_rag) {
           adsb_wave_sync();                                    // every lane's commit stores lie in front of the rewrite below
           for (int i = lane; i < kWTile; i += 64) s_x[kFwd + i] = xg<MODE>(cold()->data, cold()->n, t0 + kFwd + i, a.scale);
-          process_tile(it, t0, true, lane, BoolC<false>{}, 0u);        // (rare: at most two tiles per launch; masks from the window)
-        } else {
-          process_tile(it, t0, active, lane, BoolC<MASKS>{}, bm_regs);
+          active = true;
         }
+        process_tile(it, t0, active, lane, MASKS && it < it_rag, bm_regs);
       }
     };
     // A chunk with a number of tiles that is not a multiple of D ends inside the unrolled body: the steps past its end still
@@ -1331,7 +1345,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
       const int lane = adsb_opaque(lane_outer);
       const long long t0 = c0 + (long long)it * kWTile;
       for (int i = lane; i < kWTile; i += 64) s_x[kFwd + i] = xg<MODE>(cold()->data, cold()->n, t0 + kFwd + i, a.scale);
-      process_tile(it, t0, true, lane, BoolC<false>{}, 0u);
+      process_tile(it, t0, true, lane, false, 0u);
     }
   }
   // what the stage still holds (the whole list of a usual chunk): to global memory, in one go

@@ -123,3 +123,59 @@ if "--small" in sys.argv:
             fr.tags_out.clear()
             dm.messages.clear()
         print("blocks, %-26s framer.work %.2f us, paired demod.work %.2f us" % (name + ":", tf / 2000 * 1e6, td / 2000 * 1e6))
+
+if "--breakdown" in sys.argv:
+    # where a megasample pair's time goes: the C entry point without / with the fused pass-through, the block around it
+    # (tags), the paired demod (PDUs, pass-through)
+    from gr_adsb_amd import _native
+    for N in (1 << 18, 1 << 20, 1 << 22):
+        ctx = _native.Context(fs, 0.01, flags=_native.FLAG_FRAMER_SLICES)
+        out = np.empty(N, np.float32)
+        arr = buf[:N + H - 1]
+        reps = max(4, (1 << 25) // N)
+        res = {}
+        for name, kw in (("C call, no pass-through", {}), ("C call + fused pass-through", {"out0": out})):
+            for _ in range(3):
+                ctx.framer_work(arr, N, 0, **kw)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                b = ctx.framer_work(arr, N, 0, **kw)
+            res[name] = (time.perf_counter() - t0) / reps * 1e3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out[:] = arr[H - 1:]
+        res["numpy out0[:] = in0"] = (time.perf_counter() - t0) / reps * 1e3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.host_copy(out, x[:N])
+        res["adsb_host_copy (copy threads)"] = (time.perf_counter() - t0) / reps * 1e3
+        pin = _native.PinnedArray(N + H - 1, np.float32, near=ctx)
+        pin.array[:] = arr
+        for _ in range(3):
+            ctx.framer_work(pin.array, N, 0, out0=out)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.framer_work(pin.array, N, 0, out0=out)
+        res["C call + fused pass-through, page-locked input"] = (time.perf_counter() - t0) / reps * 1e3
+        fr = blocks.framer(fs, 0.01)
+        dm = blocks.demod(fs, framer=fr)
+        tf = td = 0.0
+        for k in range(-2, reps):
+            fr._nread = fr._nwritten = 0
+            t1 = time.perf_counter()
+            fr.work([arr], [out])
+            t2 = time.perf_counter()
+            dm.tags_in = list(fr.tags_out)
+            dm._nread = dm._nwritten = 0
+            t3 = time.perf_counter()
+            dm.work([arr[H - 1:]], [out])
+            t4 = time.perf_counter()
+            if k >= 0:
+                tf += t2 - t1
+                td += t4 - t3
+            ntag, npdu = len(fr.tags_out), len(dm.messages)
+            fr.tags_out.clear()
+            dm.messages.clear()
+        res["framer.work (block: + %d tags)" % ntag] = tf / reps * 1e3
+        res["paired demod.work (block: %d PDUs + pass-through)" % npdu] = td / reps * 1e3
+        print("chunk %d samples: " % N + "; ".join("%s %.3f ms" % kv for kv in res.items()), flush=True)

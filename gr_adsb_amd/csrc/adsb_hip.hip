@@ -311,7 +311,7 @@ struct adsb_ctx {
   hipEvent_t ext_ev[kMaxExt] = {nullptr, nullptr, nullptr, nullptr};
   int n_ext = 0;
   hipStream_t h2d_stream = nullptr;   // host-fed submissions: sample uploads, back to back on their own stream
-  hipStream_t d2h_stream = nullptr;   // record copies of passes whose own streams are shared with later passes (created on first use)
+  hipStream_t d2h_stream = nullptr;   // record copies of in-line passes while slot 2's stream holds an overlapped pass (created on first use)
   bool split_tail = false;
   bool own_stream = false;
   int n_cu = 256;
@@ -652,8 +652,8 @@ int enqueue(adsb_ctx* c, Slot& s, const Plan& pl, bool submitted) {
       //    end for the next launch to fill, and two instruction-bound launches side by side slow each other down (int8,
       //    2^30 samples: 0.568 ms in line, 0.607-0.617 overlapped; at 2^28 samples the same either way, below that the
       //    overlap wins by up to 20 %: profiles/r05_ab_8bit_workgroup_shape_and_schedule.txt).
-      // No stream is added for the kernels: slot 0's stream takes every k_detect, slot 1's every tail (the record copies have
-      // the context's copy stream, finish) -- because the runtime multiplexes all streams of a process onto FOUR
+      // No stream is added for that: the three slot streams take the three roles -- slot 0's every k_detect, slot 1's every
+      // tail, slot 2's the record copies (finish) -- because the runtime multiplexes all streams of a process onto FOUR
       // hardware queues (GPU_MAX_HW_QUEUES), and a k_detect stream that shares its queue with a stream whose tail waits for
       // that k_detect stalls behind it: with a fourth stream for k_detect the timed 2^28-sample legs ran 10 % slower than
       // in round 4 (profiles/r05_pass_cost_timed_with_a_fourth_stream.txt).
@@ -836,11 +836,16 @@ int finish(adsb_ctx* c, Slot& s, Summary* sum, int32_t* n_res) {
       // on the pass's own stream (idle: its last kernel has completed); never on a caller-owned one
       // (a submitted pass that shares its stream with the passes behind it -- kernels in line, or ADSB_FLAG_SINGLE_STREAM --
       // copies on the context's record-copy stream: on its own one the copy would wait for everything queued since)
-      // (a copy stream of its own, not a slot's: a slot's stream may hold a LATER pass -- slot 2's own overlapped pass, an
-      // in-line pass's tail -- and the copy of an older pass would wait for it)
+      // Slot 2's stream is free for that in a context whose passes are all in line (timed contexts; bulk 8-bit / > 4 GiB
+      // streams) -- and it keeps the context at three busy streams, one hardware queue each (a fourth busy stream shares a
+      // queue with one of the three and serialises behind it: the 8-bit legs ran 6 % slower with a copy stream of their own,
+      // profiles/r06_ab_record_copy_stream.txt).  Only when slot 2 itself holds an overlapped pass (a context that mixes in-line
+      // and overlapped passes) would the copy of an older pass wait for that younger one: then a copy stream of its own.
       const bool shared = s.ds != s.cs || (s.submitted && !c->split_tail);
-      if (c->own_stream && shared && !c->d2h_stream) FINCHK(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
-      const hipStream_t xs = !c->own_stream ? c->copy_stream : (shared ? c->d2h_stream : s.cs);
+      const Slot& s2 = c->slot[2];
+      const bool slot2_taken = &s2 != &s && s2.busy && s2.ds == s2.stream;
+      if (c->own_stream && shared && slot2_taken && !c->d2h_stream) FINCHK(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+      const hipStream_t xs = !c->own_stream ? c->copy_stream : (shared ? (slot2_taken ? c->d2h_stream : c->slot[2].stream) : s.cs);
       if (!in_host)
         FINCHK(hipMemcpyAsync(s.h_out, s.d_out.p, (size_t)nres * sizeof(Rec), hipMemcpyDeviceToHost, xs));
       if (c->flags & ADSB_FLAG_CONFIDENCE) {

@@ -1394,3 +1394,31 @@ def test_polled_small_passes_never_show_stale_or_partial_records(native):
     st = ctx.stats()
     assert st["poll_fallbacks"] <= 60, st          # the short spin catches (nearly) every such call on an idle GPU
     ctx.close()
+
+
+def test_record_copy_of_an_in_line_pass_while_slot_two_holds_an_overlapped_pass(native, torch_mod):
+    """Round 6 (advisor): the record copy of an IN-LINE pass -- here an int8 pass of 1 GiB in an untimed context -- normally rides
+    on slot 2's idle stream; when slot 2 itself holds a younger, overlapped pass the copy must not queue behind it: the context
+    then uses a copy stream of its own.  Big pass into slot 0, two small ones into slots 1 and 2, collected in order; every result
+    equals the blocking call's."""
+    from gr_adsb_amd import modulator as M
+    torch = torch_mod
+    fs = 2e6
+    small = M.synth_iq(1 << 20, fs, 3000, seed=61)
+    q_small = np.clip(np.round(small.view(np.float32) * 32.0), -127, 127).astype(np.int8).reshape(-1, 2)
+    t_small = torch.from_numpy(q_small).to("cuda:0")
+    reps = (1 << 29) // len(q_small)                            # 2^29 samples x 2 bytes = 1 GiB: the in-line policy of the 8-bit formats
+    t_big = t_small.repeat(reps, 1).contiguous()
+    ctx = native.Context(fs, 0.01)
+    ctx.set_format_scale(native.FMT_SC8, 1.0 / 32.0)
+    want_small = ctx.process_format_device(native.FMT_SC8, t_small.data_ptr(), len(q_small))
+    want_big = ctx.process_format_device(native.FMT_SC8, t_big.data_ptr(), t_big.shape[0])
+    assert len(want_small) > 1000 and len(want_big) > reps * (len(want_small) - 2)
+    for rep in range(2):
+        tb = ctx.submit_format_device(native.FMT_SC8, t_big.data_ptr(), t_big.shape[0])
+        t1 = ctx.submit_format_device(native.FMT_SC8, t_small.data_ptr(), len(q_small))
+        t2 = ctx.submit_format_device(native.FMT_SC8, t_small.data_ptr(), len(q_small))
+        assert ctx.wait(tb).tobytes() == want_big.tobytes()
+        assert ctx.wait(t1).tobytes() == want_small.tobytes()
+        assert ctx.wait(t2).tobytes() == want_small.tobytes()
+    ctx.close()

@@ -966,10 +966,12 @@ def main():
                 result["host_fed"] = hf_multi
             if cfg4 is not None:
                 result["config4_20msps"] = cfg4
-            if not args.no_one_process and not one_gpu:
-                # ONE process driving every GPU of the node from one host ring (the other ranks are idle at the closing barrier)
+            if not args.no_one_process:
+                # ONE process driving every GPU of the node from one host ring (the other ranks are idle at the closing barrier;
+                # ADSB_BENCH_ONE_GPU=1: the same with every context on cuda:0)
                 try:
-                    result["one_process"] = one_process_leg(args, list(range(min(n_gpus, torch.cuda.device_count()))))
+                    result["one_process"] = one_process_leg(args, [0] * n_gpus if one_gpu else
+                                                            list(range(min(n_gpus, torch.cuda.device_count()))))
                 except Exception as e:                           # noqa: BLE001  (the headline line must not be lost)
                     result["one_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_cpu and n_gpus == 1 and not intfmt:

@@ -108,7 +108,7 @@ def test_bench_eight_ranks_one_gpu_all_seven_seams():
     env = dict(os.environ, ADSB_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1",
-           "--log2n", "22", "--fs", "20e6", "--bursts", "3000", "--min-time", "0.02", "--no-config4"]
+           "--log2n", "22", "--fs", "20e6", "--bursts", "3000", "--min-time", "0.02", "--no-config4", "--no-one-process"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -128,11 +128,17 @@ def test_bench_plain_launch_starts_its_own_ranks_and_carries_config4():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--log2n", "23",
-           "--min-time", "0.05", "--extra-steps", "4", "--extra-min-time", "0.05", "--no-host-fed-multi"]
+           "--min-time", "0.05", "--extra-steps", "4", "--extra-min-time", "0.05", "--no-host-fed-multi", "--hostfed-log2n", "23"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["launched_by"].startswith("bench.py itself")
+    # ... and the leg in which rank 0 ALONE drives every device from one host ring (adsb_process_sharded_multi; here two
+    # contexts on cuda:0): identical to one blocking call, reported per shard count
+    op = d["one_process"]
+    assert "error" not in op and op["runs"][0]["contexts"] == 2
+    assert all(l_["identical_to_one_blocking_call"] and l_["value"] > 0 for l_ in op["runs"][0]["legs"])
+    assert d["config"]["one_process_2ctx_identical"] is True and d["config"]["one_process_2ctx_msps"] > 0
     assert d["config"]["seams_identical"] is True and d["config"]["rank_sync"] == "gloo"
     c4 = d["config4_20msps"]
     assert c4["fs"] == 20e6 and c4["rank_sync"] == "gloo"

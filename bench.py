@@ -328,7 +328,7 @@ def format_legs(args, dev, depth):
     # two tiles in flight), scale 4/127 the generic int8 instance (convert, multiply: what any other scale runs)
     for name, fmt, scale in (("mag2", _native.FMT_MAG2, None), ("sc16", _native.FMT_SC16, 4.0 / 32767.0),
                              ("sc8", _native.FMT_SC8, 4.0 / 128.0), ("sc8g", _native.FMT_SC8, 4.0 / 127.0),
-                             ("cu8", _native.FMT_CU8, 4.0 / 255.0)):
+                             ("cu8", _native.FMT_CU8, 4.0 / 255.0), ("cu8p", _native.FMT_CU8, 2.0 ** -6)):
         fe = FrontEnd(fs, args.threshold, device=dev.index, timing=True)
         q = quantise_for(fmt, base, fe, scale=scale)
         torch.cuda.synchronize()
@@ -336,13 +336,15 @@ def format_legs(args, dev, depth):
         rec = {"name": "format_" + name, "format": name, "bytes_per_sample": _native.FMT_BYTES[fmt],
                "workload": "BASELINE config 2's signal as %s; 2^%d samples per step resident in HBM" % (
                    {"mag2": "float32 |IQ|^2", "sc16": "int16 IQ", "sc8": "int8 IQ (scale 2^-5: dot-product instance)",
-                    "sc8g": "int8 IQ (scale 4/127: generic int8 instance)", "cu8": "uint8 offset-binary IQ"}[name], log2n),
-               "kernel_instance": {"sc8": "k_detect<int8, power-of-two scale>", "sc8g": "k_detect<int8, any scale>"}.get(name, "k_detect<%s>" % name),
+                    "sc8g": "int8 IQ (scale 4/127: generic int8 instance)", "cu8": "uint8 offset-binary IQ (scale 4/255: generic instance)",
+                    "cu8p": "uint8 offset-binary IQ (scale 2^-6: dot-product instance)"}[name], log2n),
+               "kernel_instance": {"sc8": "k_detect<int8, power-of-two scale>", "sc8g": "k_detect<int8, any scale>",
+                                   "cu8": "k_detect<uint8, any scale>", "cu8p": "k_detect<uint8, power-of-two scale>"}.get(name, "k_detect<%s>" % name),
                "value": round(n / ms / 1e3, 1), "unit": "Msamples/s", "ms_per_step": round(ms, 4), "bursts_per_step": int(nb),
                "roofline": roofline_of(st, name, iso_ms),
                "product_default": untimed_context_ms(args, dev.index, fmt, q, n, depth, torch.cuda.synchronize, fs=fs, scale=scale,
                                                      steps=args.extra_steps)}
-        tr, tr_src = pmc_traffic("sc8" if name == "sc8g" else name, fs, 1000.0, False, log2n)
+        tr, tr_src = pmc_traffic({"sc8g": "sc8", "cu8p": "cu8"}.get(name, name), fs, 1000.0, False, log2n)
         rec["roofline"]["traffic"] = tr
         rec["roofline"]["traffic_source"] = tr_src or "none for this workload (see profiles/)"
         host = q[:cpu_n].cpu().numpy()
@@ -351,7 +353,7 @@ def format_legs(args, dev, depth):
         elif name == "sc16":
             x = O.mag2_iq16(host.reshape(-1), scale)
         else:
-            x = O.mag2_iq8(host.reshape(-1), float(np.float32(scale)), name == "cu8")
+            x = O.mag2_iq8(host.reshape(-1), float(np.float32(scale)), name in ("cu8", "cu8p"))
         crecs = C.canonical(x, sps, np.float32(args.threshold))
         grecs = fe.ctx.process_format_device(fmt, q.data_ptr(), cpu_n)
         rec["bit_match"] = {"sample_bursts": int(len(crecs)), "identical": recs_match(grecs, crecs),
@@ -379,8 +381,11 @@ def quantise_for(fmt, iq, fe, scale=None):
         fe.ctx.set_format_scale(fmt, 4.0 / 128.0)
         return torch.clamp(torch.round(iq * (128.0 / 4.0)), -128, 127).to(torch.int8).contiguous()
     if fmt == _native.FMT_CU8:
-        fe.ctx.set_format_scale(fmt, 4.0 / 255.0)
-        return torch.clamp(torch.floor(iq * (127.5 / 4.0) + 128.0), 0, 255).to(torch.uint8).contiguous()
+        # component = (2 u8 - 255) * scale: default full scale 4.0 (4/255); a power-of-two scale (2^-6: the RTL-SDR style
+        # (u8 - 127.5) / 32) selects the library's dot-product instance for offset-binary bytes
+        sc = 4.0 / 255.0 if scale is None else scale
+        fe.ctx.set_format_scale(fmt, sc)
+        return torch.clamp(torch.floor(iq * (0.5 / sc) + 128.0), 0, 255).to(torch.uint8).contiguous()
     if fmt == _native.FMT_MAG2:
         return (iq[:, 0] * iq[:, 0] + iq[:, 1] * iq[:, 1]).contiguous()
     return iq
@@ -722,6 +727,8 @@ def main():
     ap.add_argument("--sc8-generic", action="store_true",
                     help="with --format sc8: scale 4/127 instead of 2^-5, i.e. k_detect's generic int8 instance (any scale) instead "
                          "of the dot-product one (power-of-two scales)")
+    ap.add_argument("--cu8-pow2", action="store_true",
+                    help="with --format cu8: scale 2^-6 instead of 4/255, i.e. k_detect's dot-product instance for offset-binary bytes")
     ap.add_argument("--format", choices=["fc32", "mag2", "sc16", "sc8", "cu8"], default="fc32",
                     help="input sample format: complex64 (BASELINE workload), float32 |IQ|^2 (the framer's literal input, "
                          "4 B/sample), int16 IQ (4 B/sample) or 8-bit IQ (2 B/sample: int8 / RTL-SDR offset binary); "
@@ -858,7 +865,8 @@ def main():
         iq = gen_stream_blocks(n_own, 0, fs, args.bursts, args.seed, dev, **synth)
         # |IQ|^2 of the same stream (separately rounded products) / the stream quantised to the integer wire
         # format (full scale 4.0; the kernel converts with the same scale), computed once outside the timed region
-        iq = quantise_for(fmt, iq, fe, scale=4.0 / 127.0 if (args.sc8_generic and args.format == "sc8") else None)
+        alt_scale = 4.0 / 127.0 if (args.sc8_generic and args.format == "sc8") else (2.0 ** -6 if (args.cu8_pow2 and args.format == "cu8") else None)
+        iq = quantise_for(fmt, iq, fe, scale=alt_scale)
         torch.cuda.synchronize()
         pending = []          # tickets of submitted, not yet collected passes (pipeline of DEPTH passes)
         last_n = [0]
@@ -888,8 +896,7 @@ def main():
         iso_ms = isolated_kernel_ms(fe, fmt, iq, n_own)
         # ... and the same pipeline on a context WITHOUT ADSB_FLAG_TIMING (the product default: no event pair between
         # consecutive k_detect launches), a few repeats right behind the timed ones
-        untimed = untimed_context_ms(args, local_rank, fmt, iq, n_own, DEPTH, sync_all,
-                                     scale=4.0 / 127.0 if (args.sc8_generic and args.format == "sc8") else None)
+        untimed = untimed_context_ms(args, local_rank, fmt, iq, n_own, DEPTH, sync_all, scale=alt_scale)
     else:
         leg = sharded_leg(args, dev, rank, n_gpus, fs, args.bursts, args.seed, n_own, args.steps, args.warmup, args.min_time,
                           DEPTH, sync_all, reduce_max, ag_int, ag_obj, synth, fe=fe,

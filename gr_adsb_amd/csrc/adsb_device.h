@@ -176,6 +176,11 @@ __device__ __forceinline__ float mag2_iq16(unsigned iq, float scale) {
 // f32(i*i + q*q) * scale^2 bit for bit, and the tile loop takes the integer sum of squares from ONE v_dot4_i32_i8 per
 // sample (body_convert); everything outside the tile loop converts as MODE 3 does.
 constexpr int kModeSc8Pow2 = 5;
+// MODE 6 = MODE 4 whose scale is a power of two (the RTL-SDR convention (u8 - 127.5) / 128 = (2*u8 - 255) * 2^-8): again every
+// intermediate of the float chain is exact -- odd integers |c| <= 255 times 2^-k, their squares, the sum of two (< 2^18 *
+// 2^-2k) -- and with x = u8 - 128 (the byte with its top bit flipped, read as a signed byte) c = 2x + 1, so
+// c_i^2 + c_q^2 = 4 (x_i^2 + x_q^2 + x_i + x_q) + 2: two v_dot4c_i32_i8 per sample (x.x and x.1) in the tile loop (body_convert).
+constexpr int kModeCu8Pow2 = 6;
 template <int MODE>
 __device__ __forceinline__ float mag2_iq8(unsigned iq, float scale) {
   if constexpr (MODE == 3 || MODE == kModeSc8Pow2) {
@@ -191,7 +196,7 @@ __device__ __forceinline__ float mag2_iq8(unsigned iq, float scale) {
   }
 }
 
-constexpr bool mode_is_iq8(int mode) { return mode == 3 || mode == 4 || mode == 5; }
+constexpr bool mode_is_iq8(int mode) { return mode == 3 || mode == 4 || mode == 5 || mode == 6; }
 constexpr int det_waves(int mode) { return mode_is_iq8(mode) ? 1 : kWaves; }      // wavefronts per k_detect workgroup
 constexpr int mode_bytes(int mode) { return mode == 0 ? 8 : mode_is_iq8(mode) ? 2 : 4; }   // bytes per sample
 
@@ -203,6 +208,7 @@ template <> struct RawSel<2> { using type = unsigned; };
 template <> struct RawSel<3> { using type = unsigned short; };
 template <> struct RawSel<4> { using type = unsigned short; };
 template <> struct RawSel<5> { using type = unsigned short; };
+template <> struct RawSel<6> { using type = unsigned short; };
 
 template <int MODE>
 __device__ __forceinline__ typename RawSel<MODE>::type load_raw(const void* data, long long i) {
@@ -857,6 +863,26 @@ __device__ __forceinline__ void body_convert(const float4& q, float scale, float
       m[2 * j] = __builtin_fmaf(__builtin_bit_cast(float, a0), s2, c23);
       m[2 * j + 1] = __builtin_fmaf(__builtin_bit_cast(float, a1), s2, c23);
     }
+  } else if constexpr (MODE == kModeCu8Pow2) {
+    // offset binary, power-of-two scale: t = x.x + x.1 over the sample's two bytes (x = byte ^ 0x80 as a signed byte;
+    // x^2 + x = x (x + 1) >= 0, t <= 2 * 128 * 127), accumulated onto the bit pattern of 2^23 like the int8 instance;
+    // |IQ|^2 = (4 t + 2) s2 = fma(2^23 + t, 4 s2, (2 - 2^25) s2): 2^25 - 2 has 24 significant bits, every step is exact.
+    // The second sample of a word takes all four bytes onto 2 * bits(2^23) minus the first result.
+    const unsigned u[4] = {__builtin_bit_cast(unsigned, q.x), __builtin_bit_cast(unsigned, q.y),
+                           __builtin_bit_cast(unsigned, q.z), __builtin_bit_cast(unsigned, q.w)};
+    const float s2 = __fmul_rn(scale, scale);
+    const float s4 = __fmul_rn(4.0f, s2), c25 = __fmul_rn(-33554430.0f, s2);
+    constexpr unsigned kTwo23 = 0x4B000000u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned x = u[j] ^ 0x80808080u;
+      unsigned a0 = (unsigned)adsb_sdot4((int)x, (int)(x & 0x0000FFFFu), (int)kTwo23);
+      a0 = (unsigned)adsb_sdot4((int)x, 0x00000101, (int)a0);
+      unsigned a1 = (unsigned)adsb_sdot4((int)x, (int)x, (int)(2u * kTwo23 - a0));
+      a1 = (unsigned)adsb_sdot4((int)x, 0x01010101, (int)a1);
+      m[2 * j] = __builtin_fmaf(__builtin_bit_cast(float, a0), s4, c25);
+      m[2 * j + 1] = __builtin_fmaf(__builtin_bit_cast(float, a1), s4, c25);
+    }
   } else {
     const unsigned u[4] = {__builtin_bit_cast(unsigned, q.x), __builtin_bit_cast(unsigned, q.y),
                            __builtin_bit_cast(unsigned, q.z), __builtin_bit_cast(unsigned, q.w)};
@@ -1295,7 +1321,7 @@ __device__ __forceinline__ void detect_body(const DetectArgs& a, const int block
     // two -- the narrow formats are NOT short of bytes in flight; kept where it pays for its 50 % more code (measured again
     // in round 6 on the kernels with register-built masks: generic int8 -1 %, uint8 -1.5 % with two tiles ahead:
     // profiles/r06_ab_8bit_masks_median.txt).
-    constexpr int D = (MODE == kModeSc8Pow2) ? 2 : 1;
+    constexpr int D = (MODE == kModeSc8Pow2 || MODE == kModeCu8Pow2) ? 2 : 1;
     Body<MODE> body[D];
     if (ntile > 0) {
       body_issue(body[0], it_rag > 0 ? nb : clamp, lane);

@@ -512,6 +512,8 @@ void launch_detect(adsb_ctx* c, hipStream_t st, const DetectArgs& a, int grid) {
   const unsigned dyn = c->det_dyn_lds[MODE];
   // int8 IQ with a power-of-two scale (x / 128 and the like): the instance whose tile loop squares with v_dot4_i32_i8
   if (MODE == ADSB_FMT_SC8 && scale_is_pow2(a.scale)) launch_detect_k<kModeSc8Pow2>(st, dyn, a, grid);
+  // uint8 IQ with a power-of-two scale ((u8 - 127.5) / 128 and the like): the same for offset-binary bytes
+  else if (MODE == ADSB_FMT_CU8 && scale_is_pow2(a.scale)) launch_detect_k<kModeCu8Pow2>(st, dyn, a, grid);
   else launch_detect_k<MODE>(st, dyn, a, grid);
 }
 template <int MODE>

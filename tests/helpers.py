@@ -189,12 +189,12 @@ def grc_instantiate(descriptor, **overrides):
     return blk, callbacks
 
 
-def every_byte_pair_stream(scale, slot=256):
+def every_byte_pair_stream(scale, slot=256, quiet=0):
     """int8 IQ, 2 Msps: slot k holds 100 samples of byte pair W_k (a constant noise window), one zero, then a preamble
     whose four high chips are byte pair V_k = k (i = low byte, q = high byte) -- every pair once as a record's peak and
     once as its median.  Returns (iq8, threshold): the threshold lies below the smallest non-zero |IQ|^2."""
     k = np.arange(65536, dtype=np.int64)
-    pair = np.zeros((65536 * slot,), dtype=np.uint16)
+    pair = np.full((65536 * slot,), quiet, dtype=np.uint16)      # (quiet = 0x8080: the resting level of offset-binary bytes)
     w = ((k * 40503 + 12345) & 0xFFFF).astype(np.uint16)
     base = k * slot
     for j in range(20, 120):

@@ -94,13 +94,14 @@ int sim_run(int mode, const float* data, long long n, long long in0_base, long l
   }
   // like adsb_hip.hip: launch_detect(): int8 IQ with a power-of-two scale runs the dot-product instance
   int fe = 0;
-  const bool pow2 = mode == 3 && frexpf(scale, &fe) == 0.5f && fe > -50 && fe < 50;
-  if (!one_launch) switch (pow2 ? 5 : mode) {
+  const bool pow2 = (mode == 3 || mode == 4) && frexpf(scale, &fe) == 0.5f && fe > -50 && fe < 50;
+  if (!one_launch) switch (pow2 ? (mode == 3 ? 5 : 6) : mode) {
     case 0: SIM_DETECT(0) break;
     case 1: SIM_DETECT(1) break;
     case 2: SIM_DETECT(2) break;
     case 3: SIM_DETECT(3) break;
     case 5: SIM_DETECT(5) break;
+    case 6: SIM_DETECT(6) break;
     default: SIM_DETECT(4) break;
   }
 #undef SIM_DETECT
@@ -177,13 +178,14 @@ void sim_set_confidence_out(float* p) { g_conf_out = p; }
 void sim_set_tail_mode(int m) { g_tail_mode = m; }
 
 // k_detect's own conversion of one 16-byte load (body_convert) for the 8-bit formats: words[4*k .. 4*k+4) -> out[8*k .. 8*k+8).
-// mode 3 int8, 4 offset-binary uint8, 5 the power-of-two-scale int8 instance (v_dot4c_i32_i8, see adsb_device.h).
+// mode 3 int8, 4 offset-binary uint8, 5 / 6 their power-of-two-scale instances (v_dot4c_i32_i8, see adsb_device.h).
 void sim_convert8(int mode, const unsigned* words, long long nwords, float scale, float* out) {
   for (long long k = 0; k + 4 <= nwords; k += 4) {
     float4 q;
     memcpy(&q, words + k, 16);
     if (mode == 3) body_convert<3>(q, scale, out + 2 * k);
     else if (mode == 4) body_convert<4>(q, scale, out + 2 * k);
+    else if (mode == 6) body_convert<kModeCu8Pow2>(q, scale, out + 2 * k);
     else body_convert<kModeSc8Pow2>(q, scale, out + 2 * k);
   }
 }

@@ -192,13 +192,13 @@ def test_kernel_resources_keep_the_tail_co_resident():
     alloc = lambda v: -(-v // 8) * 8                                    # noqa: E731  (allocation granule: 8 VGPRs)
     gran = lambda b: -(-b // GRAN) * GRAN                               # noqa: E731  (LDS allocation granule on gfx950)
     detect = {k: v for k, v in res.items() if "k_detect" in k}
-    assert len(detect) == 30            # (5 input formats + int8 with a power-of-two scale) x 5 samples-per-chip instances
+    assert len(detect) == 35            # (5 input formats + int8 and uint8 with a power-of-two scale) x 5 samples-per-chip instances
     tail = {k: v for k, v in res.items() if any(t in k for t in ("k_order", "k_resolve", "k_count", "k_compact"))}
     assert len(tail) == 8                                               # k_order per input format + three format-blind kernels
     for name, d in detect.items():
         assert d["scratch_bytes_per_lane"] == 0 and d["vgpr_spills"] == 0, name + ": spills in the streaming kernel"
         mode = int(re.search(r"k_detectILi(\d)E", name).group(1))
-        wpb = 1 if mode in (3, 4, 5) else 4                             # adsb_device.h: det_waves
+        wpb = 1 if mode in (3, 4, 5, 6) else 4                          # adsb_device.h: det_waves
         wg_cu = min(LDS_CU // gran(d["lds_bytes_per_block"]), SIMDS * (VGPR_SIMD // alloc(d["vgprs"])) // wpb, 32)
         assert wg_cu == (21 if wpb == 1 else 5), (name, wg_cu)            # 8-bit: six LDS granules per wavefront
         free_lds = LDS_CU - wg_cu * gran(d["lds_bytes_per_block"])

@@ -182,6 +182,25 @@ def test_int8_every_byte_pair_as_peak_and_as_median(native, scale):
     ctx.close()
 
 
+@pytest.mark.parametrize("scale", [2.0 ** -8, 2.0 ** -6, 8.0, 3.0 / 256.0])
+def test_uint8_every_byte_pair_as_peak_and_as_median(native, scale):
+    """The same stream read as offset-binary uint8 IQ: all 65536 (i, q) byte pairs as peak and as median against the C oracle
+    on the oracle's conversion f32(2 u8 - 255) * scale.  Power-of-two scales ((u8 - 127.5) / 128 = 2^-8: the RTL-SDR convention)
+    run k_detect<6, .>: x.x + x.1 by two v_dot4c_i32_i8 per sample, x = u8 - 128 (adsb_device.h body_convert); 3/256 the generic chain."""
+    from oracle import adsb_oracle as O
+    from oracle import c_oracle as C
+    iq8, _ = every_byte_pair_stream(1.0, quiet=0x8080)
+    u8 = iq8.view(np.uint8)
+    x = O.mag2_iq8(u8, float(np.float32(scale)), True)
+    thr = np.float32(6.0) * np.float32(scale) * np.float32(scale)           # between the resting |IQ|^2 (2 s^2: bytes 127 / 128) and the next (10 s^2)
+    want = C.canonical(x, 2, thr)
+    assert len(want) >= 60000, len(want)
+    ctx = native.Context(2e6, float(thr))
+    ctx.set_format_scale(native.FMT_CU8, float(scale))
+    assert_recs_equal(ctx.process_format(native.FMT_CU8, u8), want, "every byte pair, offset binary, scale %g" % scale)
+    ctx.close()
+
+
 @pytest.mark.parametrize("sps", [2, 8])
 def test_output_stage_with_lists_of_eighty_entries(native, sps):
     """k_detect's LDS output stage (adsb_device.h: Stage; complex64, |IQ|^2 floats, int16) holds sixteen records: a train of
@@ -231,7 +250,7 @@ def test_canonical_int16_iq_matches_reference_goldens(native, torch_mod, name):
     assert_recs_match_golden(ctx.wait(tk), g)
 
 
-@pytest.mark.parametrize("fmt_name,scale", [("sc8", 1.0 / 128.0), ("sc8", 1.0 / 127.0), ("cu8", 1.0 / 255.0)])
+@pytest.mark.parametrize("fmt_name,scale", [("sc8", 1.0 / 128.0), ("sc8", 1.0 / 127.0), ("cu8", 1.0 / 255.0), ("cu8", 1.0 / 256.0)])
 @pytest.mark.parametrize("fs", [2e6, 8e6, 6e6])
 def test_every_rise_a_tile_can_have_8bit_formats(native, torch_mod, fmt_name, scale, fs):
     """Up to 512 rises per 1024-sample tile -- every rise a tile can have -- with matched preambles all over them, through the
@@ -261,19 +280,20 @@ def test_every_rise_a_tile_can_have_8bit_formats(native, torch_mod, fmt_name, sc
     ctx.close()
 
 
-@pytest.mark.parametrize("fs,bps", [(2e6, 2000), (8e6, 6000), (20e6, 2000)])
-@pytest.mark.parametrize("fmt", ["sc8", "cu8"])
+@pytest.mark.parametrize("fs,bps", [(2e6, 2000), (8e6, 6000), (20e6, 2000), (12e6, 3000)])
+@pytest.mark.parametrize("fmt", ["sc8", "cu8", "cu8p"])
 def test_int8_iq_formats_vs_c_oracle(native, torch_mod, fs, bps, fmt):
     """8-bit IQ ingestion (ADSB_FMT_SC8 / ADSB_FMT_CU8) -- host, device and submitted entry points
-    against the oracle fed with the oracle's own exact conversion of the same bytes."""
+    against the oracle fed with the oracle's own exact conversion of the same bytes.  cu8p: offset binary with a
+    power-of-two scale, (2 u8 - 255) * 2^-6: the dot-product instance k_detect<6, .> (round 6)."""
     from gr_adsb_amd import modulator as M
     from oracle import adsb_oracle as O
     from oracle import c_oracle as C
-    ob = fmt == "cu8"
+    ob = fmt != "sc8"
     f = native.FMT_CU8 if ob else native.FMT_SC8
     n = (1 << 22) + 1234
     q = M.quantize_iq8(M.synth_iq(n, fs, bps, 21, noise_power=3e-3, amp2_range=(0.2, 1.0)), full_scale=4.0, offset_binary=ob)
-    scale = float(np.float32(4.0 / 255.0 if ob else 4.0 / 127.0))
+    scale = float(np.float32({"sc8": 4.0 / 127.0, "cu8": 4.0 / 255.0, "cu8p": 2.0 ** -6}[fmt]))
     ctx = native.Context(fs, 0.03)
     ctx.set_format_scale(f, scale)
     want = C.canonical(O.mag2_iq8(q, scale, ob), int(fs // 1e6), np.float32(0.03))

@@ -489,7 +489,9 @@ def test_int8_power_of_two_scale_conversion_every_byte_pair(scale):
         got = simlib.convert8(mode, iq8, scale)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), mode
     u8 = words.view(np.uint8)
-    assert np.array_equal(simlib.convert8(4, u8, scale).view(np.uint32), O.mag2_iq8(u8, scale, True).view(np.uint32))
+    want_u = O.mag2_iq8(u8, scale, True)
+    for mode in (4, 6):          # 6: the offset-binary power-of-two instance (two dot products per sample: x.x and x.1, x = u8 - 128)
+        assert np.array_equal(simlib.convert8(mode, u8, scale).view(np.uint32), want_u.view(np.uint32)), mode
 
 
 def test_int8_power_of_two_scale_every_byte_pair_through_the_kernels():
@@ -502,6 +504,14 @@ def test_int8_power_of_two_scale_every_byte_pair_through_the_kernels():
     recs, so = simlib.sim_canonical(3, seg, 2e6, float(thr), scale=1.0 / 128.0)
     assert so.overflow == 0
     assert_recs_equal(recs, want, "every byte pair")
+    # the same bytes read as offset binary with the RTL-SDR scale (u8 - 127.5) / 128 = (2 u8 - 255) * 2^-8: k_detect<6, .>
+    u8 = seg.view(np.uint8)
+    xu = O.mag2_iq8(u8, 2.0 ** -8, True)
+    thr_u = np.float32(0.75) * np.float32(2.0 ** -16) * np.float32(2.0)          # below the smallest |IQ|^2 (2 * 2^-16)
+    want_u = C.canonical(xu, 2, thr_u)
+    recs, so = simlib.sim_canonical(4, u8, 2e6, float(thr_u), scale=2.0 ** -8)
+    assert so.overflow == 0
+    assert_recs_equal(recs, want_u, "every byte pair, offset binary")
 
 
 @pytest.mark.parametrize("fs,bps", [(2e6, 5000), (8e6, 6000), (12e6, 4000)])
@@ -564,7 +574,7 @@ def test_signed_zeros_in_the_noise_window_match_the_reference(name):
         assert np.array_equal(snr_bits(recs["peak"], recs["median"]), g.get("random", "tag_snr_bits"))
 
 
-@pytest.mark.parametrize("mode,scale", [(3, 1.0 / 128.0), (3, 1.0 / 127.0), (4, 1.0 / 255.0)])
+@pytest.mark.parametrize("mode,scale", [(3, 1.0 / 128.0), (3, 1.0 / 127.0), (4, 1.0 / 255.0), (4, 1.0 / 256.0)])
 @pytest.mark.parametrize("fs", [2e6, 4e6, 6e6])
 def test_every_rise_a_tile_can_have_8bit_formats(mode, scale, fs):
     """Streams with up to 512 rises per tile -- every rise a tile can have -- and matched preambles all over them, through the

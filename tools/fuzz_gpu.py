@@ -150,9 +150,10 @@ def run(budget, seed, max_n=None):
             else:
                 ob = fmt == _native.FMT_CU8
                 q = M.quantize_iq8(iqf, full_scale=2.0, offset_binary=ob)
-                # int8: half of the cases with a power-of-two scale (the dot-product instance of k_detect), half with 2/127
-                # (the generic int8 instance)
-                scale = float(np.float32(2.0 / 255.0 if ob else (2.0 / 128.0 if rng.random() < 0.5 else 2.0 / 127.0)))
+                # half of the cases with a power-of-two scale (the dot-product instances of k_detect: int8 2/128, uint8 2/256),
+                # half with 2/127 resp. 2/255 (the generic instances)
+                p2 = rng.random() < 0.5
+                scale = float(np.float32((2.0 / 256.0 if p2 else 2.0 / 255.0) if ob else (2.0 / 128.0 if p2 else 2.0 / 127.0)))
                 xq = O.mag2_iq8(q, scale, ob)
             ctx.set_format_scale(fmt, scale)
             assert_recs_equal(ctx.process_format(fmt, q), C.canonical(xq, sps, np.float32(thr)), what + " fmt %d" % fmt)

@@ -7,7 +7,7 @@
  *
  *   adsb_create / adsb_destroy      framer.__init__ python/adsb/framer.py:37-65, demod.__init__ python/adsb/demod.py:35-54
  *   adsb_set_threshold              framer.set_threshold           python/adsb/framer.py:68-69
- *   adsb_framer_work                framer.work()                  python/adsb/framer.py:72-182
+ *   adsb_framer_work[_passthrough]  framer.work()                  python/adsb/framer.py:72-182 (_passthrough: incl. :181 out0[:] = in0)
  *   adsb_demod_work                 demod.work()                   python/adsb/demod.py:57-136
  *   adsb_process_iq[_device]        complex_to_mag_squared -> framer -> demod as wired in
  *                                   examples/adsb_rx.py:180-196 (one canonical work() call per block)
@@ -15,6 +15,7 @@
  *   adsb_submit_*_device / adsb_wait   the same, up to ADSB_MAX_IN_FLIGHT calls in flight (no reference counterpart: pipelining)
  *   adsb_submit_format_host         the same fed from host memory: the SDR source -> framer chain of examples/adsb_rx.py:113-126,180-196
  *   adsb_last_confidence            demod.bit_confidence           python/adsb/demod.py:97-101
+ *   adsb_device_alloc / _free / _upload   (no reference counterpart: device memory for C / ctypes clients of the *_device entries)
  *   adsb_shard_device / adsb_shard_fixup / adsb_stitch   (no reference counterpart: overlapped time shards, host stitch)
  *   adsb_process_sharded_multi      the single process of examples/adsb_rx.py:242-268 (one flowgraph, one IQ source) fed to
  *                                   N devices: one host ring in, one stitched burst list out (ABI 5)

@@ -30,6 +30,65 @@ _FEW = 6                                  # bursts per work() call up to which t
 _F10, _F16, _INF = np.float32(10.0), np.float32(1.6), np.float32(np.inf)
 
 
+# Page-locking the buffer a work() call's input is a view OF (round 6): the library DMA's a page-locked source where it lies
+# (adsb_process_* / adsb_framer_work: ~0.13 instead of ~0.21 ms per megasample call, small calls are read in place over PCIe)
+# instead of copying it through its staging buffers first.  A work() call only sees a slice; what can be page-locked ONCE is the
+# array that owns the memory -- found through the slice's .base chain.  That is the case for file replay, tests and any
+# Python-side driver that hands slices of one ring; the real GNU Radio gateway wraps the scheduler's buffer in a fresh
+# array per call with no owner to find, so nothing is registered there (an application that owns such a ring registers it
+# itself: adsb_host_register / _native.RegisteredArray).  Registrations end when the owning array dies.
+_PIN_MIN, _PIN_MAX, _PIN_SLOTS = 1 << 20, 1 << 32, 8
+_pinned_roots = {}
+_pin_lock = threading.Lock()
+
+
+def pin_source(arr):
+    """Page-lock (once) the ndarray that owns arr's memory, if there is one of 1 MiB .. 4 GiB; no-op otherwise."""
+    root = arr
+    while isinstance(getattr(root, "base", None), np.ndarray):
+        root = root.base
+    if root is arr and arr.base is not None:
+        return False                                              # a view of something that is not an ndarray: no owner to find
+    if not isinstance(root, np.ndarray) or not root.flags.owndata or not root.flags.c_contiguous:
+        return False
+    if not (_PIN_MIN <= root.nbytes <= _PIN_MAX):
+        return False
+    key = root.ctypes.data
+    with _pin_lock:
+        if key in _pinned_roots:
+            return True
+        if len(_pinned_roots) >= _PIN_SLOTS:
+            return False
+        import ctypes
+        lib = _native.load()
+        # (no reference to the array is kept: the registration must not keep its owner alive -- it ends WITH it)
+        if lib.adsb_host_register(ctypes.c_void_p(key), root.nbytes) != 0:
+            return False                                          # (already registered by the application, or not lockable)
+        _pinned_roots[key] = root.nbytes
+    import weakref
+    try:
+        weakref.finalize(root, _unpin, key)
+    except TypeError:                                             # (an ndarray subclass without weak references: lock it for good)
+        pass
+    return True
+
+
+def _unpin(key):
+    import ctypes
+    with _pin_lock:
+        had = _pinned_roots.pop(key, None)
+    if had is not None:
+        _native.load().adsb_host_unregister(ctypes.c_void_p(key))
+
+
+def unpin_all():
+    """Drop every registration pin_source made (they also end one by one when their owning arrays die)."""
+    with _pin_lock:
+        keys = list(_pinned_roots)
+    for k in keys:
+        _unpin(k)
+
+
 def make_pdu(start_timestamp, fs, offset, snr, bits112):
     """The PDU the reference demod publishes for one burst (demod.py:104-110): a pair
     (dict{"timestamp": start + offset/fs, "snr": snr}, u8vector of 112 0/1 values) -- what decoder.py:330-335
@@ -137,8 +196,10 @@ class _SliceStore:
 class framer(gr.sync_block):
     """ADS-B preamble detector / tagger (reference python/adsb/framer.py:33-182)."""
 
-    def __init__(self, fs, threshold, device=0, improved=False, long_aware=False, min_chunk=0):
-        """min_chunk (extension, default 0 = whatever the scheduler hands over, like the reference): when > 0 the block asks
+    def __init__(self, fs, threshold, device=0, improved=False, long_aware=False, min_chunk=0, pin_inputs=True):
+        """pin_inputs (extension, default on): page-lock, once, the array that owns the memory a work() call's input is a slice
+        of (pin_source above); harmless where no such owner exists (the real GNU Radio gateway).
+        min_chunk (extension, default 0 = whatever the scheduler hands over, like the reference): when > 0 the block asks
         the scheduler for work() calls of a multiple of that many items (gr.basic_block.set_output_multiple): a call costs
         tens of microseconds whatever its size, so large chunks are what lifts the block from tens of Msamples/s to
         Gsamples/s (tools/gr_latency.py).  Chunking is the scheduler's freedom in the reference too (framer.py:72-77);
@@ -182,6 +243,8 @@ class framer(gr.sync_block):
         self._ctx = _native.Context(fs, threshold, device=device,
                                     flags=(_native.FLAG_LONG_AWARE_GATE if self.long_aware else 0) |
                                           (0 if self.improved else _native.FLAG_FRAMER_SLICES))
+        self.pin_inputs = bool(pin_inputs)
+        self._pin_seen = None             # address of the last owner looked at (one dictionary lookup per call at most)
         self._slices = _SliceStore()      # bits of the bursts this block's pass already sliced, for a paired demod
         self._paired = False              # set by demod(fs, framer=self): only then are the slices kept
         self._pmt_key, self._pmt_src = pmt.to_pmt("burst"), pmt.to_pmt("framer")
@@ -237,6 +300,11 @@ class framer(gr.sync_block):
         self._ctx.set_threshold_cached(self.threshold)
         if self.improved:
             return self._work_improved(in0, out0)
+        if self.pin_inputs and in0.nbytes >= (64 << 10):
+            b = in0.base
+            if b is not None and id(b) != self._pin_seen:
+                self._pin_seen = id(b)
+                pin_source(in0)
         # chunks of 256 KiB and more: the pass-through copy (framer.py:181) runs inside the library beside the device pass
         fused_copy = out0.nbytes >= _FUSE_COPY_BYTES and out0.flags.c_contiguous and out0.dtype == np.float32
         bursts = self._ctx.framer_work(in0[:N + self.N_hist - 1], N, self.nitems_written(0), out0=out0 if fused_copy else None)

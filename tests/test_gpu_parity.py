@@ -1442,3 +1442,40 @@ def test_record_copy_of_an_in_line_pass_while_slot_two_holds_an_overlapped_pass(
         assert ctx.wait(t1).tobytes() == want_small.tobytes()
         assert ctx.wait(t2).tobytes() == want_small.tobytes()
     ctx.close()
+
+
+def test_work_inputs_are_page_locked_once_through_their_owning_array(native):
+    """Round 6: framer.work() page-locks, once, the array its input is a slice of (blocks.pin_source), so that the library DMA's
+    the samples where they lie; tags and PDUs are the same with and without, the registration ends with the owning array, and a
+    slice without an ndarray owner (what the real GNU Radio gateway hands over) is left alone."""
+    import gc
+    from gr_adsb_amd import blocks, grshim
+    from gr_adsb_amd import modulator as M
+    from oracle import adsb_oracle as O
+    fs = 2e6
+    blocks.unpin_all()                                             # (arrays other tests keep alive may hold the eight slots)
+    x = O.mag2(M.synth_iq(1 << 21, fs, 3000, seed=15))
+    sched = [1 << 18] * 8
+    outs = []
+    for pin in (False, True):
+        fr, dm = blocks.framer(fs, 0.01, pin_inputs=pin), blocks.demod(fs)
+        dm.start_timestamp = 0.0
+        xx = x.copy()
+        before = len(blocks._pinned_roots)
+        tags, msgs = grshim.drive(fr, dm, xx, sched)
+        outs.append(([(t_.offset, float(t_.value[1])) for t_ in tags], [m[1].tobytes() for _, m in msgs]))
+        assert len(tags) > 1000
+        del fr, dm, tags, msgs, xx
+        gc.collect()
+        assert len(blocks._pinned_roots) == before                 # dropped with the owning array (or never made)
+    assert outs[0] == outs[1]
+    big = np.zeros(1 << 20, np.float32)
+    assert blocks.pin_source(big[100:5000]) is True and big.ctypes.data in blocks._pinned_roots
+    assert blocks.pin_source(big[7:]) is True and len([k for k in blocks._pinned_roots if k == big.ctypes.data]) == 1
+    import ctypes
+    raw = (ctypes.c_float * 4096)()
+    assert blocks.pin_source(np.frombuffer(raw, dtype=np.float32)) is False        # no ndarray owner, too small anyway
+    assert blocks.pin_source(np.zeros(100, np.float32)) is False
+    del big
+    gc.collect()
+    assert not blocks._pinned_roots

@@ -27,9 +27,11 @@ H = 8 * sps
 buf = np.concatenate([np.zeros(H - 1, np.float32), x])
 print("# fs %g Msps, 1000 bursts/s, host buffers (pageable numpy arrays, as GNU Radio hands them over); gc.freeze() after imports: %s"
       % (fs / 1e6, "--no-freeze" not in sys.argv))
+PIN = "--no-pin" not in sys.argv        # page-lock, once, the array the work() inputs are slices of (blocks.pin_source)
+print("# inputs page-locked once through their owning array (blocks.pin_source): %s" % PIN)
 for paired in (False, True):
     for N in (2048, 8192, 32768, 262144, 1 << 20, 1 << 22, 1 << 24):
-        fr = blocks.framer(fs, 0.01)
+        fr = blocks.framer(fs, 0.01, pin_inputs=PIN)
         dm = blocks.demod(fs, framer=fr if paired else None)
         out = np.empty(N, np.float32)
         tf = td = 0.0

@@ -1726,7 +1726,11 @@ int collect_shard(adsb_ctx* c, int32_t ticket, std::vector<adsb_burst>* out) {
   c->last_slot = ticket;
   if ((r = shard_post(c, s, sum, &nres))) return r;
   const adsb_burst* recs = (const adsb_burst*)s.h_out;
-  out->assign(recs, recs + nres);
+  try {
+    out->assign(recs, recs + nres);
+  } catch (...) {                                     // (no exception crosses the ABI or ends a feeder thread)
+    return fail(c, -ENOMEM, "shard records");
+  }
   return 0;
 }
 
@@ -1757,7 +1761,15 @@ int adsb_process_sharded_multi(adsb_ctx* const* ctxs, int32_t n_ctx, int fmt, co
   const int G = n_ctx * shards_per_ctx;
   const auto t_start = std::chrono::steady_clock::now();
 
-  std::vector<MultiShard> sh((size_t)G);
+  std::vector<MultiShard> sh;
+  std::vector<double> feed_s;
+  std::vector<std::thread> th;
+  std::vector<char> joined;
+  try {
+    sh.resize((size_t)G); feed_s.assign((size_t)n_ctx, 0.0); th.reserve((size_t)n_ctx); joined.assign((size_t)n_ctx, 0);
+  } catch (...) {
+    return fail(c0, -ENOMEM, "adsb_process_sharded_multi: shard table");
+  }
   for (int g = 0; g < G; ++g) {
     int64_t olo, ohi, lo, hi;
     const int rc = adsb_shard_bounds(n, G, g, sps, 4096, &olo, &ohi, &lo, &hi);
@@ -1766,7 +1778,6 @@ int adsb_process_sharded_multi(adsb_ctx* const* ctxs, int32_t n_ctx, int fmt, co
   }
   std::mutex m;
   std::condition_variable cv;
-  std::vector<double> feed_s((size_t)n_ctx, 0.0);
 
   // context k's feeder: its shards, ADSB_MAX_IN_FLIGHT deep.  An error ends this feeder only (its remaining shards are
   // marked done with the error) -- and nothing of its context stays in flight behind it.
@@ -1814,11 +1825,20 @@ int adsb_process_sharded_multi(adsb_ctx* const* ctxs, int32_t n_ctx, int fmt, co
     feed_s[(size_t)k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   };
 
-  std::vector<std::thread> th;
-  std::vector<char> joined((size_t)n_ctx, 0);
-  th.reserve((size_t)n_ctx);
-  for (int k = 0; k < n_ctx; ++k) th.emplace_back(feeder, k);
-  auto join_one = [&](int k) { if (!joined[(size_t)k]) { th[(size_t)k].join(); joined[(size_t)k] = 1; } };
+  for (int k = 0; k < n_ctx; ++k) {
+    try {
+      th.emplace_back(feeder, k);
+    } catch (...) {
+      // no thread for this context (resource limit): its shards fail, the others still run and are collected
+      th.emplace_back();                                     // (keeps th[k] <-> context k; reserve() above: cannot throw)
+      joined[(size_t)k] = 1;
+      for (int g = k * shards_per_ctx; g < (k + 1) * shards_per_ctx; ++g) {
+        { std::lock_guard<std::mutex> lk(m); sh[(size_t)g].rc = -ENOMEM; sh[(size_t)g].done = true; }
+      }
+      (void)fail(ctxs[k], -ENOMEM, "adsb_process_sharded_multi: could not start the feeder thread");
+    }
+  }
+  auto join_one = [&](int k) { if (!joined[(size_t)k]) { if (th[(size_t)k].joinable()) th[(size_t)k].join(); joined[(size_t)k] = 1; } };
 
   // the calling thread: finished shards in stream order, head fix-up with the carried state, records to `out`
   long long eob = -(1ll << 60);

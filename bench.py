@@ -324,11 +324,13 @@ def format_legs(args, dev, depth):
     base = gen_stream_blocks(n, 0, fs, 1000.0, args.seed, dev)
     torch.cuda.synchronize()
     out = []
-    # int8 twice: scale 2^-5 selects the dot-product instance of k_detect (k_detect<sc8, power-of-two scale>: v_dot4c_i32_i8,
+    # int8 and uint8 twice each: a power-of-two scale (2^-5 / 2^-6: the usual int8 convention / the RTL-SDR one) selects the
+    # dot-product instance of k_detect for the format, any other scale (4/127, 4/255: sc8g / cu8g) the generic instance.
+    # int8: scale 2^-5 selects the dot-product instance of k_detect (k_detect<sc8, power-of-two scale>: v_dot4c_i32_i8,
     # two tiles in flight), scale 4/127 the generic int8 instance (convert, multiply: what any other scale runs)
     for name, fmt, scale in (("mag2", _native.FMT_MAG2, None), ("sc16", _native.FMT_SC16, 4.0 / 32767.0),
                              ("sc8", _native.FMT_SC8, 4.0 / 128.0), ("sc8g", _native.FMT_SC8, 4.0 / 127.0),
-                             ("cu8", _native.FMT_CU8, 4.0 / 255.0), ("cu8p", _native.FMT_CU8, 2.0 ** -6)):
+                             ("cu8", _native.FMT_CU8, 2.0 ** -6), ("cu8g", _native.FMT_CU8, 4.0 / 255.0)):
         fe = FrontEnd(fs, args.threshold, device=dev.index, timing=True)
         q = quantise_for(fmt, base, fe, scale=scale)
         torch.cuda.synchronize()
@@ -336,15 +338,15 @@ def format_legs(args, dev, depth):
         rec = {"name": "format_" + name, "format": name, "bytes_per_sample": _native.FMT_BYTES[fmt],
                "workload": "BASELINE config 2's signal as %s; 2^%d samples per step resident in HBM" % (
                    {"mag2": "float32 |IQ|^2", "sc16": "int16 IQ", "sc8": "int8 IQ (scale 2^-5: dot-product instance)",
-                    "sc8g": "int8 IQ (scale 4/127: generic int8 instance)", "cu8": "uint8 offset-binary IQ (scale 4/255: generic instance)",
-                    "cu8p": "uint8 offset-binary IQ (scale 2^-6: dot-product instance)"}[name], log2n),
+                    "sc8g": "int8 IQ (scale 4/127: generic int8 instance)", "cu8": "uint8 offset-binary IQ (scale 2^-6, the RTL-SDR convention (u8 - 127.5) / 32 at this full scale: dot-product instance)",
+                    "cu8g": "uint8 offset-binary IQ (scale 4/255: generic uint8 instance)"}[name], log2n),
                "kernel_instance": {"sc8": "k_detect<int8, power-of-two scale>", "sc8g": "k_detect<int8, any scale>",
-                                   "cu8": "k_detect<uint8, any scale>", "cu8p": "k_detect<uint8, power-of-two scale>"}.get(name, "k_detect<%s>" % name),
+                                   "cu8": "k_detect<uint8, power-of-two scale>", "cu8g": "k_detect<uint8, any scale>"}.get(name, "k_detect<%s>" % name),
                "value": round(n / ms / 1e3, 1), "unit": "Msamples/s", "ms_per_step": round(ms, 4), "bursts_per_step": int(nb),
                "roofline": roofline_of(st, name, iso_ms),
                "product_default": untimed_context_ms(args, dev.index, fmt, q, n, depth, torch.cuda.synchronize, fs=fs, scale=scale,
                                                      steps=args.extra_steps)}
-        tr, tr_src = pmc_traffic({"sc8g": "sc8", "cu8p": "cu8"}.get(name, name), fs, 1000.0, False, log2n)
+        tr, tr_src = pmc_traffic({"sc8g": "sc8", "cu8g": "cu8"}.get(name, name), fs, 1000.0, False, log2n)
         rec["roofline"]["traffic"] = tr
         rec["roofline"]["traffic_source"] = tr_src or "none for this workload (see profiles/)"
         host = q[:cpu_n].cpu().numpy()
@@ -353,7 +355,7 @@ def format_legs(args, dev, depth):
         elif name == "sc16":
             x = O.mag2_iq16(host.reshape(-1), scale)
         else:
-            x = O.mag2_iq8(host.reshape(-1), float(np.float32(scale)), name in ("cu8", "cu8p"))
+            x = O.mag2_iq8(host.reshape(-1), float(np.float32(scale)), name in ("cu8", "cu8g"))
         crecs = C.canonical(x, sps, np.float32(args.threshold))
         grecs = fe.ctx.process_format_device(fmt, q.data_ptr(), cpu_n)
         rec["bit_match"] = {"sample_bursts": int(len(crecs)), "identical": recs_match(grecs, crecs),
@@ -381,9 +383,10 @@ def quantise_for(fmt, iq, fe, scale=None):
         fe.ctx.set_format_scale(fmt, 4.0 / 128.0)
         return torch.clamp(torch.round(iq * (128.0 / 4.0)), -128, 127).to(torch.int8).contiguous()
     if fmt == _native.FMT_CU8:
-        # component = (2 u8 - 255) * scale: default full scale 4.0 (4/255); a power-of-two scale (2^-6: the RTL-SDR style
-        # (u8 - 127.5) / 32) selects the library's dot-product instance for offset-binary bytes
-        sc = 4.0 / 255.0 if scale is None else scale
+        # component = (2 u8 - 255) * scale.  Default: the RTL-SDR convention (u8 - 127.5) / 2^k -- here full scale 4.0, 2^-6 --
+        # a power-of-two scale, which also selects the library's dot-product instance for offset-binary bytes; any other scale
+        # (--cu8-generic: 4/255) runs the generic uint8 instance
+        sc = 2.0 ** -6 if scale is None else scale
         fe.ctx.set_format_scale(fmt, sc)
         return torch.clamp(torch.floor(iq * (0.5 / sc) + 128.0), 0, 255).to(torch.uint8).contiguous()
     if fmt == _native.FMT_MAG2:
@@ -727,8 +730,10 @@ def main():
     ap.add_argument("--sc8-generic", action="store_true",
                     help="with --format sc8: scale 4/127 instead of 2^-5, i.e. k_detect's generic int8 instance (any scale) instead "
                          "of the dot-product one (power-of-two scales)")
-    ap.add_argument("--cu8-pow2", action="store_true",
-                    help="with --format cu8: scale 2^-6 instead of 4/255, i.e. k_detect's dot-product instance for offset-binary bytes")
+    ap.add_argument("--cu8-generic", action="store_true",
+                    help="with --format cu8: scale 4/255 instead of 2^-6, i.e. k_detect's generic uint8 instance (any scale) instead of "
+                         "the dot-product one (power-of-two scales: the RTL-SDR convention)")
+    ap.add_argument("--cu8-pow2", action="store_true", help=argparse.SUPPRESS)      # (the default since round 6; kept for old scripts)
     ap.add_argument("--format", choices=["fc32", "mag2", "sc16", "sc8", "cu8"], default="fc32",
                     help="input sample format: complex64 (BASELINE workload), float32 |IQ|^2 (the framer's literal input, "
                          "4 B/sample), int16 IQ (4 B/sample) or 8-bit IQ (2 B/sample: int8 / RTL-SDR offset binary); "
@@ -865,7 +870,7 @@ def main():
         iq = gen_stream_blocks(n_own, 0, fs, args.bursts, args.seed, dev, **synth)
         # |IQ|^2 of the same stream (separately rounded products) / the stream quantised to the integer wire
         # format (full scale 4.0; the kernel converts with the same scale), computed once outside the timed region
-        alt_scale = 4.0 / 127.0 if (args.sc8_generic and args.format == "sc8") else (2.0 ** -6 if (args.cu8_pow2 and args.format == "cu8") else None)
+        alt_scale = 4.0 / 127.0 if (args.sc8_generic and args.format == "sc8") else (4.0 / 255.0 if (args.cu8_generic and args.format == "cu8") else None)
         iq = quantise_for(fmt, iq, fe, scale=alt_scale)
         torch.cuda.synchronize()
         pending = []          # tickets of submitted, not yet collected passes (pipeline of DEPTH passes)

@@ -27,11 +27,15 @@ WL=(
  "fmt_mag2|--format mag2"
  "fmt_sc16|--format sc16"
  "fmt_sc8|--format sc8"
- "fmt_cu8|--format cu8"
+ "fmt_cu8|--format cu8 --cu8-generic"
+ "fmt_cu8p|--format cu8"
 )
+# (fmt_cu8 = the generic uint8 instance, any scale; fmt_cu8p = the dot-product instance, the bench's default uint8 leg since
+#  round 6.)  ONLY=<name> in the environment: that workload alone, without the closing SQ / full-bench steps.
 cd /tmp
 for w in "${WL[@]}"; do
   name=${w%%|*}; args=${w#*|}
+  [ -n "${ONLY:-}" ] && [ "$ONLY" != "$name" ] && continue
   # 1. kernel trace (default pipeline: tail kernels on their own stream, three passes in flight)
   $S $W/$name.kt.clk -- rocprofv3 --kernel-trace --stats -d $W/kt_$name -o kt -- $B $args --steps 10 --warmup 3 --min-time 0.2 > $W/kt_$name.log 2>&1
   DB=$(find $W/kt_$name -name '*.db' | head -1)
@@ -73,6 +77,7 @@ for l in sys.stdin:
   (cd $ROOT && $S $W/$name.plain.clk -- $B $args > $OUT/${R}_${name}_bench.json 2>> $W/bench.err; cat $W/$name.plain.clk >> $OUT/${R}_${name}_bench.json)
   [ "${2:-}" = quick ] && break
 done
+[ -n "${ONLY:-}" ] && { ls -la $OUT; exit 0; }
 # 4. SQ counters (waits / issue / instruction mix), headline workload
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -f csv -d $W/sq1 -o p -- $B --steps 4 --warmup 1 --min-time 0 > $W/sq1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace -f csv -d $W/sq2 -o p -- $B --steps 4 --warmup 1 --min-time 0 > $W/sq2.log 2>&1

@@ -12,7 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W = [("cfg2_2msps_fc32", "cfg2 2 Msps complex64 (2^30)"), ("cfg3_8msps_dense_fc32", "cfg3 8 Msps dense (2^28)"),
      ("cfg4_20msps_fc32", "cfg4 20 Msps (2^28)"), ("cfg5_mixed_df_fc32", "cfg5 mixed DF (2^28)"),
-     ("fmt_mag2", "\\|IQ\\|² floats (2^30)"), ("fmt_sc16", "int16 (2^30)"), ("fmt_sc8", "int8 (2^30)"), ("fmt_cu8", "uint8 (2^30)")]
+     ("fmt_mag2", "\\|IQ\\|² floats (2^30)"), ("fmt_sc16", "int16 (2^30)"), ("fmt_sc8", "int8 (2^30)"), ("fmt_cu8", "uint8, any scale (2^30)"),
+     ("fmt_cu8p", "uint8, power-of-two scale (2^30)")]
 
 
 def rows(path, key):
@@ -29,6 +30,8 @@ def main(r):
           "| unprofiled pipelined `kernel_ms` | Δ | blit copies in the pipelined trace (calls, total ms) |")
     print("|---|---|---|---|---|---|---|---|")
     for w, label in W:
+        if not os.path.exists(os.path.join(P, "%s_%s_bench.json" % (r, w))):
+            continue                                           # (a workload this round's set does not hold)
         b = rows(os.path.join(P, "%s_%s_kernel_trace_blocking.txt" % (r, w)), "k_detect")
         p = rows(os.path.join(P, "%s_%s_kernel_trace.txt" % (r, w)), "k_detect")
         c = rows(os.path.join(P, "%s_%s_kernel_trace.txt" % (r, w)), "copyBuffer")
@@ -40,6 +43,8 @@ def main(r):
             c["calls"] if c else 0, c["total"] / 1e3 if c else 0.0))
     print()
     for w, label in W:
+        if not os.path.exists(os.path.join(P, "%s_%s_bench.json" % (r, w))):
+            continue                                           # (a workload this round's set does not hold)
         d = json.loads(open(os.path.join(P, "%s_%s_bench.json" % (r, w))).readline())
         ro = d["roofline"]
         print("%-28s value %9.1f Msps  step %.4f ms  frac %.4f live / %.4f isolated" % (w, d["value"], d["ms_per_step"], ro["frac"], ro["isolated"]["frac"]))

@@ -1117,7 +1117,7 @@ def untimed_context_ms(args, device, fmt, iq, n, depth, sync_all, repeats=3, fs=
     if fmt not in (0, 1):
         # the integer wire formats convert with the scale the timed context was given (quantise_for)
         fe2.ctx.set_format_scale(fmt, scale if scale is not None else
-                                 {_native.FMT_SC16: 4.0 / 32767.0, _native.FMT_SC8: 4.0 / 128.0, _native.FMT_CU8: 4.0 / 255.0}[fmt])
+                                 {_native.FMT_SC16: 4.0 / 32767.0, _native.FMT_SC8: 4.0 / 128.0, _native.FMT_CU8: 2.0 ** -6}[fmt])
     pend = []
     for _ in range(3):
         fe2.ctx.process_format_device(fmt, iq.data_ptr(), n, 0, fetch=False)

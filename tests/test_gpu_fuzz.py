@@ -18,3 +18,13 @@ def test_bounded_fuzz_against_the_oracles(seed0):
     import fuzz_gpu
     res = fuzz_gpu.run(10.0, seed0, max_n=1 << 20)
     assert res["cases"] >= 100 and res["bursts"] > 0, res
+
+
+def test_bounded_8bit_fuzz_aimed_at_the_narrow_format_kernels():
+    """tools/fuzz_sim_8bit.py through the C ABI: few-level noise floors (the exact-hint median), bursts back to back and at the
+    start of the stream (short / odd noise windows), int8 and offset-binary uint8 with power-of-two and other scales (all four
+    8-bit instances of k_detect), streams up to 3 M samples -- against the C oracle on the oracle's |IQ|^2 of the same bytes."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_sim_8bit
+    res = fuzz_sim_8bit.run(10.0, 31337, on_gpu=True)
+    assert res["cases"] >= 50 and res["bursts"] > 0 and len(res["per_instance"]) == 4, res

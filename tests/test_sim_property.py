@@ -87,3 +87,14 @@ def test_framer_work_random_schedules_equal_numpy_oracle(seed, sps):
     assert np.array_equal(snr_bits(recs["peak"], recs["median"]), o["tag_snr"].view(np.uint32))
     assert fr.prev_eob.value == o["final_prev_eob"]
     assert np.float32(fr.prev_in0.value).view(np.uint32) == np.float32(o["final_prev_in0"]).view(np.uint32)
+
+
+def test_8bit_streams_aimed_at_the_exact_hint_median_and_the_dot_product_instances():
+    """A bounded slice of tools/fuzz_sim_8bit.py on the emulator (the long runs: profiles/r06_fuzz_sim_8bit.txt): few-level noise
+    floors, bursts back to back and at the start of the stream, int8 / offset-binary uint8 with power-of-two and other scales."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_sim_8bit
+    res = fuzz_sim_8bit.run(8.0, 2718)
+    assert res["cases"] >= 50 and res["bursts"] > 0 and len(res["per_instance"]) == 4, res
